@@ -1,0 +1,114 @@
+/*
+ * slb_oracle.h -- CPU oracle for the super-lattice Boltzmann stepping loop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference CPU
+ * solver (reference: src/boltzmann_c_solver.c) that the parity tests, the smoke
+ * check and the benchmark's cpu_baseline leg use as the checker.  Nothing in
+ * the shipped GPU path may include, link or call it.
+ *
+ * PINNING STATUS: the reference holds no tests, golden vectors or fixtures for
+ * this path, and its CPU solver cannot be compiled in this image (it includes
+ * <gsl/gsl_specfunc.h>; GSL is absent).  The only anchor is one display=4
+ * output line of the compiled reference recorded when the reference was
+ * surveyed (tests/golden/config1_display4_reference.txt).  Beyond that line:
+ * PARITY UNPINNED.
+ */
+#ifndef SLB_ORACLE_H
+#define SLB_ORACLE_H
+
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Run parameters.  The first block is what the command line sets
+ * (reference: src/boltzmann_cli.c:105-122); the second block is derived by
+ * orc_derive() the way the reference main() does
+ * (reference: src/boltzmann_c_solver.c:100-113). */
+typedef struct orc_params {
+  int   N;        /* n-harmonics: rows 0..N, rows 0..N-1 are updated            */
+  int   M;        /* g-grid: columns 0..M+2, columns 1..M+1 (1..M) are updated  */
+  float E_dc, E_omega, omega, mu, alpha, B, PhiYmin, PhiYmax, dt, t_start;
+
+  float dPhi, nu, nu2, nu_tilde, bdt;
+  int   MSIZE;    /* row pitch in floats = M+3 (CPU layout, no padding)          */
+  int   TMSIZE;   /* M+1                                                         */
+} orc_params;
+
+void orc_derive(orc_params *p);
+
+/* Modified Bessel function of the first kind, integer order (stands where the
+ * reference calls GSL: src/boltzmann_c_solver.c:118, 247-248, 312-313). */
+double orc_bessel_In(int n, double x);
+
+/* Equilibrium coefficients a0[n][m], n=0..N, m=0..M+2
+ * (reference: src/boltzmann_c_solver.c:116-122). */
+void orc_init_a0(const orc_params *p, float *a0);
+
+/* One sweep over local columns j_first..j_last of a slab whose local column 0
+ * is global column m_offset, row pitch `pitch` floats.  With m_offset=0,
+ * pitch=MSIZE this is the loop body shared by the reference's two sweeps
+ * (reference: src/boltzmann_c_solver.c:361-380 and :391-409). */
+void orc_sweep(const orc_params *p, int pitch, int m_offset, int j_first, int j_last,
+               const float *a0, const float *a_c, const float *b_c,
+               const float *a_s, const float *b_s, float *a_out, float *b_out,
+               float cos_omega_t, float cos_omega_t_plus_dt);
+
+/* reference: src/boltzmann_c_solver.c:355-382 */
+void orc_step_on_grid(const orc_params *p, const float *a0,
+                      const float *a_current, const float *b_current,
+                      float *a_next, float *b_next,
+                      const float *a_current_hs, const float *b_current_hs,
+                      float cos_omega_t, float cos_omega_t_plus_dt);
+
+/* reference: src/boltzmann_c_solver.c:384-411 */
+void orc_step_on_half_grid(const orc_params *p, const float *a0,
+                           const float *a_next, const float *b_next,
+                           const float *a_current_hs, const float *b_current_hs,
+                           float *a_next_hs, float *b_next_hs,
+                           float cos_omega_t, float cos_omega_t_plus_dt);
+
+/* reference: src/boltzmann_c_solver.c:413-437.  av_data has 6 floats. */
+void orc_av(const orc_params *p, const float *a, const float *b, float *av_data, float t);
+
+/* reference: src/boltzmann_c_solver.c:289-296 */
+float orc_eval_norm(const orc_params *p, const float *a);
+
+/* Whole-solver state: 4+4 ping-pong buffers, a0, averaging data, loop time. */
+typedef struct orc_state {
+  orc_params p;
+  float *a0, *a[4], *b[4];
+  float av_data[6];
+  int   current, next, current_hs, next_hs;
+  float t, t0, t_max, T, frame_time;
+  long  steps_done;
+} orc_state;
+
+/* Allocate, fill a0, copy a0 into a[0], run the tiptoe half step
+ * (reference: src/boltzmann_c_solver.c:116-145).  Returns 0 on success. */
+int  orc_state_init(orc_state *s, const orc_params *p);
+void orc_state_free(orc_state *s);
+
+/* One iteration of the time loop body at loop time s->t, without any display
+ * branch (reference: src/boltzmann_c_solver.c:165-176, 193-194). */
+void orc_state_step(orc_state *s);
+
+/* The reference main(): time loop + display=4 / display=77 output
+ * (reference: src/boltzmann_c_solver.c:83-287, 298-331).  `out` receives what
+ * the reference writes to its o= file, `log` what it writes to stdout.
+ * max_steps<0 means "run to t_max". */
+int orc_solver_run(orc_state *s, int display, FILE *out, FILE *log, long max_steps);
+
+/* display=8 frame writer (reference: src/boltzmann_solver.c:487-507, the only
+ * definition that takes t; the CPU solver emits nothing for display=8). */
+void orc_print_2d_data(const orc_params *p, FILE *out, FILE *log,
+                       const float *a, const float *b, float t);
+
+void orc_set_threads(int n);
+int  orc_get_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
