@@ -1,0 +1,45 @@
+# Build of the MI355X (gfx950) solver.
+#   make            -> super-lattice-boltzmann-2d_amd/libslb2d.so, bin/boltzmann_solver, oracle
+#   make lib        -> the library only
+# The kernels need separately rounded mul/add in the reference's order:
+# -ffp-contract=off, no fast-math.  Host C is built like the reference's host
+# (gnu99, -O3, no -march: reference GNUmakefile:36).
+ROCM    ?= /opt/rocm
+HIPCC   ?= $(ROCM)/bin/hipcc
+CC      ?= gcc
+PKG     := super-lattice-boltzmann-2d_amd
+LIB     := $(PKG)/libslb2d.so
+
+HIPFLAGS := --offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 -Wall
+CFLAGS   := -std=gnu99 -O3 -fPIC -ffp-contract=off -Wall -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include
+
+HOST_SRC := $(PKG)/host/slb_globals.c $(PKG)/host/slb_bessel.c $(PKG)/host/slb_cli.c \
+            $(PKG)/host/slb_solver.c $(PKG)/host/slb_main.c
+HOST_OBJ := $(HOST_SRC:.c=.o)
+HDRS     := include/slb_abi.h $(PKG)/host/slb_host.h
+
+all: lib bin/boltzmann_solver oracle
+
+lib: $(LIB)
+
+$(PKG)/csrc/slb_kernels.o: $(PKG)/csrc/slb_kernels.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(PKG)/host/%.o: $(PKG)/host/%.c $(HDRS)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(LIB): $(PKG)/csrc/slb_kernels.o $(HOST_OBJ)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lm
+
+bin/boltzmann_solver: $(PKG)/host/boltzmann_solver.c $(LIB)
+	@mkdir -p bin
+	$(CC) $(CFLAGS) -o $@ $< -L$(PKG) -lslb2d -Wl,-rpath,'$$ORIGIN/../$(PKG)' -Wl,-rpath,$(ROCM)/lib -lm
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(PKG)/csrc/*.o $(PKG)/host/*.o $(LIB) bin/boltzmann_solver
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle clean

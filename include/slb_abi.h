@@ -1,0 +1,143 @@
+/*
+ * slb_abi.h -- C boundary of libslb2d.so (MI355X / gfx950 build of the
+ * super-lattice Boltzmann stepping loop).
+ *
+ * Part 1 re-exports, symbol for symbol, the boundary the reference's host
+ * program binds (declarations: reference src/boltzmann_gpu.h:4-29).  Part 2 is
+ * additive: the same kernels with the slab geometry spelled out (for phi_y
+ * partitioning across GPUs), halo movers, the reductions split into a
+ * partial-sum and an update stage, and launch controls.  Everything is plain C:
+ * raw device pointers, ints and floats; no C++ or torch types.
+ *
+ * All pointers named a*, b*, av_data, sums, buf are DEVICE pointers owned by the
+ * caller.  The library keeps no pointer between calls and allocates nothing
+ * per call (one small workspace is allocated on first use of the reductions).
+ * Launches are asynchronous on the stream set by slb_set_stream() (default: the
+ * null stream, as in the reference).
+ */
+#ifndef SLB_ABI_H
+#define SLB_ABI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------
+ * Part 1 -- the reference boundary
+ * ---------------------------------------------------------------------- */
+
+/* Host-owned parameters the boundary imports (reference:
+ * src/boltzmann_gpu.cu:40-44; defined by the host in src/boltzmann_cli.c:26-45
+ * and src/boltzmann_solver.c:47-65).  libslb2d.so carries the definitions so a
+ * foreign-function loader can set them; a host that links the library sets
+ * them exactly as the reference's main() does and then calls load_data(). */
+extern float host_E_dc, host_E_omega, host_omega, host_mu, host_alpha,
+             PhiYmin, PhiYmax, host_B, t_start, host_dPhi, host_dt,
+             host_bdt, host_nu_tilde, host_nu2, host_nu;
+extern int   host_M, host_N, MSIZE, MP1, NSIZE, host_TMSIZE, PADDED_MSIZE;
+
+/* Snapshot the host_* parameters for the following launches.  Re-callable at
+ * any time (reference: src/boltzmann_gpu.cu:57-82, called at
+ * src/boltzmann_solver.c:117 and again at :391). */
+void load_data(void);
+
+/* Main-lattice sweep: rows n=0..N-1, columns m=1..M+1.  centre = *_current,
+ * stencil = *_current_hs, output = *_next.  `blocks`, `t`, `t_hs` are accepted
+ * and ignored, as every reference kernel body ignores t and t_hs.
+ * (reference: src/boltzmann_gpu.cu:1169-1216; arithmetic and column range:
+ * src/boltzmann_c_solver.c:355-382) */
+void step_on_grid(int blocks, float *a0, float *a_current, float *b_current,
+                  float *a_next, float *b_next,
+                  float *a_current_hs, float *b_current_hs,
+                  float t, float t_hs, float cos_omega_t, float cos_omega_t_plus_dt);
+
+/* Half-step-lattice sweep: rows n=0..N-1, columns m=1..M.  centre =
+ * *_current_hs, stencil = *_next, output = *_next_hs.
+ * (reference: src/boltzmann_gpu.cu:1218-1265; arithmetic and column range:
+ * src/boltzmann_c_solver.c:384-411 -- the CPU range, which stops one column
+ * before the reference's CUDA kernels do) */
+void step_on_half_grid(int blocks, float *a0, float *a_current, float *b_current,
+                       float *a_next, float *b_next,
+                       float *a_current_hs, float *b_current_hs,
+                       float *a_next_hs, float *b_next_hs,
+                       float t, float t_hs, float cos_omega_t, float cos_omega_t_plus_dt);
+
+/* Harmonic reductions over m=1..M and the running averages / absorption
+ * integrals in av_data[0..5] (device, read-modify-write).
+ * (reference: src/boltzmann_gpu.cu:1267-1271; arithmetic:
+ * src/boltzmann_c_solver.c:413-437) */
+void av(int blocks, float *a, float *b, float *av_data, float t);
+
+/* Print "<error string> in <file> at line <line>" and exit(EXIT_FAILURE) when
+ * err is not hipSuccess (reference: src/boltzmann_gpu.cu:29-36; err is a
+ * hipError_t passed as int). */
+void HandleError(int err, const char *file, int line);
+
+/* ------------------------------------------------------------------------
+ * Part 2 -- additive entry points (no counterpart in the reference)
+ * ---------------------------------------------------------------------- */
+
+/* Geometry of one phi_y slab.  A single-GPU run is the slab
+ * {pitch=PADDED_MSIZE, m_offset=0, j_first=1, j_last=M+1 (or M)}. */
+typedef struct slb_slab {
+  int pitch;     /* floats per row of every array passed with this slab        */
+  int m_offset;  /* global column index of local column 0                      */
+  int j_first;   /* first local column the sweep writes                        */
+  int j_last;    /* last local column the sweep writes (inclusive)             */
+} slb_slab;
+
+/* The sweep both reference entry points reduce to: update rows 0..N-1, local
+ * columns j_first..j_last of a slab, reading the stencil arrays at local
+ * columns j-1 and j+1.  Physics parameters come from the last load_data().
+ * Returns 0, or a hipError_t value if the launch was rejected; argument
+ * errors (bad geometry, misaligned arrays for the chosen variant) return -1
+ * and print the reason. */
+int slb_sweep(const slb_slab *slab,
+              const float *a0, const float *a_centre, const float *b_centre,
+              const float *a_stencil, const float *b_stencil,
+              float *a_out, float *b_out,
+              float cos_omega_t, float cos_omega_t_plus_dt);
+
+/* Gather local column `col` of rows 0..nrows-1 of arrays a and b into
+ * buf[0..nrows-1] and buf[nrows..2*nrows-1]; and the inverse scatter. */
+int slb_halo_pack  (const float *a, const float *b, int pitch, int nrows, int col, float *buf);
+int slb_halo_unpack(float *a, float *b, int pitch, int nrows, int col, const float *buf);
+
+/* First stage of av(): the three sums over local columns j_first..j_last
+ * (b[1][m]*dPhi, a[0][m]*phi_y(m)*dPhi, a[1][m]*dPhi), terms formed in float as
+ * the reference does, accumulated in double by a wave64 shuffle tree.
+ * sums[0..2] are overwritten. */
+int slb_av_partial(const slb_slab *slab, const float *a, const float *b, double *sums);
+
+/* Second stage of av(): narrow sums[0..2] to float and apply the reference's
+ * update of av_data[0..5] at loop time t. */
+int slb_av_update(const double *sums, float *av_data, float t);
+
+/* How av() forms its three sums:
+ *   SLB_AV_EXACT (default) -- one wave per sum adds the terms one after the
+ *       other in float, in the reference's order: bit-identical to the
+ *       reference CPU av();
+ *   SLB_AV_TREE -- slb_av_partial + slb_av_update: wave64 shuffle tree in
+ *       double; differs from the CPU's sequential float sum by that sum's own
+ *       rounding noise (about 1e-6 relative at M = 2^20). */
+enum { SLB_AV_EXACT = 0, SLB_AV_TREE = 1 };
+void slb_set_av_mode(int mode);
+
+/* Stream for every launch of this library (a hipStream_t passed as void*). */
+void  slb_set_stream(void *hip_stream);
+void *slb_get_stream(void);
+
+/* Sweep kernel selection: variant 0 = auto, 1 = one column per lane,
+ * 2 = four columns per lane with neighbour columns re-read through L1,
+ * 3 = four columns per lane with neighbour columns taken from the adjacent
+ * lanes (cross-lane), 4 = like 3 with the stencil rows staged through LDS.
+ * n_chunk = rows per workgroup in n (0 = auto), block = threads (0 = auto). */
+void slb_set_tuning(int variant, int n_chunk, int block);
+
+/* Library / device identification for logs: returns a static string. */
+const char *slb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLB_ABI_H */

@@ -1,0 +1,208 @@
+"""Thin ctypes binding of libslb2d.so (HIP kernels + C host for gfx950).
+
+The product is the C library and the ``boltzmann_solver`` program; this module
+only loads the library for tests, the benchmark and the one-process-per-GPU
+driver.  It never computes anything itself and fails loudly when the library
+has not been built (``make lib`` at the repository root).
+
+Entry points bound here are the ones declared in ``include/slb_abi.h`` (the
+reference boundary: reference src/boltzmann_gpu.h:4-29) and in
+``host/slb_host.h`` (the host engine: reference src/boltzmann_solver.c:97-253).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslb2d.so")
+
+_FLOAT_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha",
+                  "PhiYmin", "PhiYmax", "host_B", "t_start", "host_dPhi", "host_dt",
+                  "host_bdt", "host_nu_tilde", "host_nu2", "host_nu", "frame_start", "t_max")
+_INT_GLOBALS = ("host_M", "host_N", "MSIZE", "MP1", "NSIZE", "host_TMSIZE", "PADDED_MSIZE",
+                "display", "quiet", "device")
+
+# every symbol include/slb_abi.h declares
+ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "HandleError",
+                 "slb_sweep", "slb_halo_pack", "slb_halo_unpack", "slb_av_partial",
+                 "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream",
+                 "slb_set_tuning", "slb_version")
+ABI_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha",
+               "PhiYmin", "PhiYmax", "host_B", "t_start", "host_dPhi", "host_dt",
+               "host_bdt", "host_nu_tilde", "host_nu2", "host_nu",
+               "host_M", "host_N", "MSIZE", "MP1", "NSIZE", "host_TMSIZE", "PADDED_MSIZE")
+
+SLB_AV_EXACT, SLB_AV_TREE = 0, 1
+
+
+class Slab(C.Structure):
+    _fields_ = [("pitch", C.c_int), ("m_offset", C.c_int), ("j_first", C.c_int), ("j_last", C.c_int)]
+
+
+class SolverStruct(C.Structure):
+    """Mirror of ``slb_solver`` in host/slb_host.h."""
+    _fields_ = [("N", C.c_int), ("M", C.c_int), ("rank", C.c_int), ("nranks", C.c_int),
+                ("W", C.c_int), ("pitch", C.c_int), ("m_offset", C.c_int),
+                ("main_slab", Slab), ("half_slab", Slab), ("av_slab", Slab),
+                ("a0", C.c_void_p), ("a", C.c_void_p * 4), ("b", C.c_void_p * 4),
+                ("av_data", C.c_void_p), ("sums", C.c_void_p), ("halo_buf", C.c_void_p),
+                ("current", C.c_int), ("next", C.c_int), ("current_hs", C.c_int), ("next_hs", C.c_int),
+                ("t", C.c_float), ("frame_time", C.c_float), ("steps", C.c_long)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it is missing (there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make lib` (hipcc --offload-arch=gfx950). "
+                "There is no CPU or eager fallback for the stepping loop.")
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        fp, vp, i, f = C.c_void_p, C.c_void_p, C.c_int, C.c_float
+        L.load_data.argtypes, L.load_data.restype = [], None
+        L.step_on_grid.argtypes = [i] + [fp] * 7 + [f] * 4
+        L.step_on_grid.restype = None
+        L.step_on_half_grid.argtypes = [i] + [fp] * 9 + [f] * 4
+        L.step_on_half_grid.restype = None
+        L.av.argtypes, L.av.restype = [i, fp, fp, fp, f], None
+        L.slb_sweep.argtypes = [C.POINTER(Slab)] + [fp] * 7 + [f, f]
+        L.slb_sweep.restype = i
+        L.slb_halo_pack.argtypes = [fp, fp, i, i, i, fp]
+        L.slb_halo_pack.restype = i
+        L.slb_halo_unpack.argtypes = [fp, fp, i, i, i, fp]
+        L.slb_halo_unpack.restype = i
+        L.slb_av_partial.argtypes = [C.POINTER(Slab), fp, fp, fp]
+        L.slb_av_partial.restype = i
+        L.slb_av_update.argtypes = [fp, fp, f]
+        L.slb_av_update.restype = i
+        L.slb_set_av_mode.argtypes, L.slb_set_av_mode.restype = [i], None
+        L.slb_set_stream.argtypes, L.slb_set_stream.restype = [vp], None
+        L.slb_get_stream.argtypes, L.slb_get_stream.restype = [], vp
+        L.slb_set_tuning.argtypes, L.slb_set_tuning.restype = [i, i, i], None
+        L.slb_version.argtypes, L.slb_version.restype = [], C.c_char_p
+        # host engine
+        L.slb_derive_and_load.argtypes, L.slb_derive_and_load.restype = [], None
+        L.slb_bessel_In.argtypes, L.slb_bessel_In.restype = [i, C.c_double], C.c_double
+        L.slb_solver_create.argtypes, L.slb_solver_create.restype = [i, i], C.POINTER(SolverStruct)
+        L.slb_solver_destroy.argtypes, L.slb_solver_destroy.restype = [C.POINTER(SolverStruct)], None
+        L.slb_solver_tiptoe.argtypes, L.slb_solver_tiptoe.restype = [C.POINTER(SolverStruct)], None
+        L.slb_solver_sweep_main.argtypes = [C.POINTER(SolverStruct), f, f]
+        L.slb_solver_sweep_main.restype = None
+        L.slb_solver_sweep_half.argtypes = [C.POINTER(SolverStruct), f, f]
+        L.slb_solver_sweep_half.restype = None
+        L.slb_solver_swap.argtypes, L.slb_solver_swap.restype = [C.POINTER(SolverStruct)], None
+        L.slb_step_cosines.argtypes, L.slb_step_cosines.restype = [f, C.POINTER(C.c_float * 4)], None
+        L.slb_solver_step.argtypes, L.slb_solver_step.restype = [C.POINTER(SolverStruct)], None
+        L.slb_solver_run_timed.argtypes = [C.POINTER(SolverStruct), i, C.POINTER(C.c_float)]
+        L.slb_solver_run_timed.restype = i
+        L.slb_solver_halo_pack.argtypes = [C.POINTER(SolverStruct), i, i, fp]
+        L.slb_solver_halo_pack.restype = i
+        L.slb_solver_halo_unpack.argtypes = [C.POINTER(SolverStruct), i, i, fp]
+        L.slb_solver_halo_unpack.restype = i
+        L.slb_solver_get_rows.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
+        L.slb_solver_get_rows.restype = i
+        _lib = L
+    return _lib
+
+
+def set_globals(**kw):
+    """Set host-owned globals by their C names (host_E_dc=..., host_M=..., ...)."""
+    L = lib()
+    for k, v in kw.items():
+        if k in _FLOAT_GLOBALS:
+            C.c_float.in_dll(L, k).value = v
+        elif k in _INT_GLOBALS:
+            C.c_int.in_dll(L, k).value = v
+        else:
+            raise KeyError(k)
+
+
+def get_global(name):
+    L = lib()
+    if name in _FLOAT_GLOBALS:
+        return C.c_float.in_dll(L, name).value
+    if name in _INT_GLOBALS:
+        return C.c_int.in_dll(L, name).value
+    raise KeyError(name)
+
+
+def configure(*, N, M, E_dc, E_omega, omega, mu, alpha, B, PhiYmin, PhiYmax, dt=0.001, t_start=1.0):
+    """What the program's command line plus slb_derive_and_load() do: set the
+    run parameters, derive dPhi / nu / bdt / pitch, snapshot them for launches."""
+    set_globals(host_N=N, host_M=M, host_E_dc=E_dc, host_E_omega=E_omega, host_omega=omega,
+                host_mu=mu, host_alpha=alpha, host_B=B, PhiYmin=PhiYmin, PhiYmax=PhiYmax,
+                host_dt=dt, t_start=t_start)
+    lib().slb_derive_and_load()
+    return {k: get_global(k) for k in ("host_dPhi", "host_nu", "host_nu2", "host_nu_tilde",
+                                       "host_bdt", "MSIZE", "PADDED_MSIZE", "NSIZE", "host_TMSIZE")}
+
+
+class Solver:
+    """One phi_y slab of the lattice on the current HIP device (host/slb_solver.c)."""
+
+    def __init__(self, rank=0, nranks=1):
+        self._p = lib().slb_solver_create(rank, nranks)
+        if not self._p:
+            raise RuntimeError("slb_solver_create failed")
+
+    @property
+    def s(self):
+        return self._p.contents
+
+    def close(self):
+        if self._p:
+            lib().slb_solver_destroy(self._p)
+            self._p = None
+
+    def tiptoe(self):
+        lib().slb_solver_tiptoe(self._p)
+
+    def step(self):
+        lib().slb_solver_step(self._p)
+
+    def sweep_main(self, c0, c1):
+        lib().slb_solver_sweep_main(self._p, c0, c1)
+
+    def sweep_half(self, c0, c1):
+        lib().slb_solver_sweep_half(self._p, c0, c1)
+
+    def swap(self):
+        lib().slb_solver_swap(self._p)
+
+    def run_timed(self, steps):
+        ms = C.c_float(0)
+        rc = lib().slb_solver_run_timed(self._p, steps, C.byref(ms))
+        if rc:
+            raise RuntimeError(f"slb_solver_run_timed -> {rc}")
+        return ms.value
+
+    def halo_pack(self, which, side, buf_ptr):
+        rc = lib().slb_solver_halo_pack(self._p, which, side, buf_ptr)
+        if rc:
+            raise RuntimeError(f"slb_solver_halo_pack -> {rc}")
+
+    def halo_unpack(self, which, side, buf_ptr):
+        rc = lib().slb_solver_halo_unpack(self._p, which, side, buf_ptr)
+        if rc:
+            raise RuntimeError(f"slb_solver_halo_unpack -> {rc}")
+
+    def rows(self, arr, row0=0, nrows=None):
+        """Rows of device array `arr` (0=a0, 1..4=a[0..3], 5..8=b[0..3]) as a numpy
+        array of shape (nrows, pitch)."""
+        import numpy as np
+        s = self.s
+        nrows = s.N + 1 - row0 if nrows is None else nrows
+        out = np.empty((nrows, s.pitch), dtype=np.float32)
+        rc = lib().slb_solver_get_rows(self._p, arr, row0, nrows, out.ctypes.data)
+        if rc:
+            raise RuntimeError(f"slb_solver_get_rows -> {rc}")
+        return out
+
+
+def step_cosines(t):
+    c = (C.c_float * 4)()
+    lib().slb_step_cosines(t, C.byref(c))
+    return tuple(c)

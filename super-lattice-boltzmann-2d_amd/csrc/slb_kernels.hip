@@ -1,0 +1,572 @@
+// slb_kernels.hip -- gfx950 (MI355X) kernels and the C boundary of libslb2d.so.
+//
+// What runs here: the two lattice sweeps of the Boltzmann stepping loop and the
+// harmonic reductions, behind the entry points declared in include/slb_abi.h.
+// Arithmetic is IEEE binary32, one rounding per operation, in the association
+// order of the reference CPU sweeps (reference: src/boltzmann_c_solver.c:363-378),
+// so that fields are bit-identical to the CPU solver.  This file must be compiled
+// with -ffp-contract=off and without any fast-math option.
+//
+// Layout: every array is [N+1][pitch] floats, row n holds harmonic n, column m
+// the phi_y grid point.  Lanes run along m (coalesced); a lane owns V adjacent
+// columns and walks n upward, keeping the differences X[r][m+1]-X[r][m-1] of the
+// two stencil rows it will need again in registers.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/slb_abi.h"
+
+// ---------------------------------------------------------------------------
+// parameters snapshotted by load_data()
+// ---------------------------------------------------------------------------
+namespace {
+
+struct Physics {
+  float E_dc, E_omega, omega, B, dt, dPhi, PhiYmin, nu, nu2, nu_tilde, bdt;
+  int   N, M, pitch, TMSIZE;
+  bool  loaded;
+};
+Physics     g_phys = {};
+hipStream_t g_stream = nullptr;
+int         g_av_mode = SLB_AV_EXACT;
+int         g_variant = 0, g_n_chunk = 0, g_block = 0;
+double     *g_ws = nullptr;          // reduction workspace, allocated once
+int         g_ws_device = -1;
+constexpr int kMaxAvBlocks = 1024;
+
+struct SweepArgs {
+  const float *a0, *a_c, *b_c, *a_s, *b_s;
+  float *a_out, *b_out;
+  float E_dc, E_omega, B, dt, dPhi, PhiYmin, nu, nu2, nu_tilde, bdt, cos_t, cos_t1;
+  int N, pitch, j_first, j_last, m_offset, n_chunk;
+};
+
+// ---------------------------------------------------------------------------
+// the point update
+// ---------------------------------------------------------------------------
+// Ap/Am (Bp/Bm): stencil arrays at row n+1, columns m+1 / m-1.
+// dA_lo/dB_lo:   A[n-1][m+1]-A[n-1][m-1] and the same for B (any value if n==0).
+__device__ __forceinline__ void point_update(
+    const SweepArgs &p, int n, float fn, float mu_part, float mu1_part,
+    float a0v, float ac, float bc, float Ap, float Am, float Bp, float Bm,
+    float dA_lo, float dB_lo, float &a_new, float &b_new)
+{
+  const float mu_t  = fn * mu_part;
+  const float mu_t1 = fn * mu1_part;
+  // g: ((dt*a0 + a*nu~) - b*mu_t) + bdt*((Bp - Bm) - [n>=2] dB_lo)
+  const float sb = (Bp - Bm) - (n < 2 ? 0.0f : dB_lo);
+  const float g  = ((p.dt * a0v + ac * p.nu_tilde) - bc * mu_t) + p.bdt * sb;
+  // h: (b*nu~ + a*mu_t) + bdt*(((chi*[n>=1] dA_lo) - Ap) + Am), chi = 2 at n==1
+  const float chi = (n == 1) ? 2.0f : 1.0f;
+  const float lo  = (n == 0) ? 0.0f : dA_lo;
+  const float sa  = ((chi * lo) - Ap) + Am;
+  const float h   = (bc * p.nu_tilde + ac * mu_t) + p.bdt * sa;
+  const float xi  = p.nu2 + mu_t1 * mu_t1;
+  a_new = (g * p.nu - h * mu_t1) / xi;
+  b_new = (g * mu_t1 + h * p.nu) / xi;
+}
+
+template <int V>
+__device__ __forceinline__ void load_v(const float *p, float (&r)[V]) {
+  if constexpr (V == 4) {
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+  } else {
+    r[0] = *p;
+  }
+}
+template <int V>
+__device__ __forceinline__ void store_v(float *p, const float (&r)[V]) {
+  if constexpr (V == 4) {
+    *reinterpret_cast<float4 *>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+    *p = r[0];
+  }
+}
+
+// One stencil row -> e[0..V+1] = columns j-1 .. j+V.
+// XCH == 0: the two outer columns are re-read from memory (they hit L1/L2).
+// XCH == 1: they come from the neighbouring lanes; only lane 0 / lane 63 of a
+//           wave read memory for them.
+template <int V, int XCH>
+__device__ __forceinline__ void load_stencil_row(const float *row, int j, int jl, int jr,
+                                                 int lane, float (&e)[V + 2])
+{
+  float body[V];
+  load_v<V>(row + j, body);
+#pragma unroll
+  for (int k = 0; k < V; k++) e[k + 1] = body[k];
+  if constexpr (XCH == 0) {
+    e[0]     = row[jl];
+    e[V + 1] = row[jr];
+  } else {
+    float edge = 0.0f;
+    if (lane == 0)  edge = row[jl];
+    if (lane == 63) edge = row[jr];
+    const float from_left  = __shfl_up(body[V - 1], 1, 64);
+    const float from_right = __shfl_down(body[0], 1, 64);
+    e[0]     = (lane == 0)  ? edge : from_left;
+    e[V + 1] = (lane == 63) ? edge : from_right;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// sweep kernel: grid.x covers columns (V per lane), grid.y covers n-chunks
+// ---------------------------------------------------------------------------
+template <int V, int XCH>
+__global__ void __launch_bounds__(256)
+sweep_kernel(const SweepArgs p)
+{
+  const int lane = threadIdx.x & 63;
+  const int jj   = (blockIdx.x * blockDim.x + threadIdx.x) * V;   // first own column
+  if (XCH == 0 && jj > p.j_last) return;
+  // lanes past the end stay alive for the cross-lane exchange; keep their
+  // addresses inside the row (pitch is a multiple of V when V > 1)
+  const int j  = jj <= p.pitch - V ? jj : p.pitch - V;
+  const int jl = j > 0 ? j - 1 : 0;
+  const int jr = j + V < p.pitch ? j + V : p.pitch - 1;
+
+  const int n0 = blockIdx.y * p.n_chunk;
+  const int n1 = n0 + p.n_chunk < p.N ? n0 + p.n_chunk : p.N;
+
+  // per-column field terms (reference: src/boltzmann_c_solver.c:363-364, macro :69)
+  float mu_part[V], mu1_part[V];
+  bool  wr[V];
+  bool  wr_all = true;
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    const int   m   = p.m_offset + jj + k;
+    const float phi = p.PhiYmin + p.dPhi * (float)(m - 1);
+    mu_part[k]  = ((p.E_dc + p.E_omega * p.cos_t)  + p.B * phi) * p.dt / 2.0f;
+    mu1_part[k] = ((p.E_dc + p.E_omega * p.cos_t1) + p.B * phi) * p.dt / 2.0f;
+    wr[k]  = (jj + k >= p.j_first) && (jj + k <= p.j_last);
+    wr_all = wr_all && wr[k];
+  }
+
+  const size_t P = (size_t)p.pitch;
+  const float *a0r = p.a0  + (size_t)n0 * P + j;
+  const float *acr = p.a_c + (size_t)n0 * P + j;
+  const float *bcr = p.b_c + (size_t)n0 * P + j;
+  float       *aor = p.a_out + (size_t)n0 * P + j;
+  float       *bor = p.b_out + (size_t)n0 * P + j;
+  const float *asr = p.a_s + (size_t)n0 * P;     // stencil rows are indexed with j, jl, jr
+  const float *bsr = p.b_s + (size_t)n0 * P;
+
+  // dA[q][k], dB[q][k]: column differences of the stencil row whose parity
+  // relative to n0 is q^1 ... set 0 holds row n0-1, set 1 holds row n0.
+  float dA[2][V], dB[2][V];
+  {
+    float e[V + 2];
+    if (n0 >= 1) {
+      load_stencil_row<V, XCH>(asr - P, j, jl, jr, lane, e);
+#pragma unroll
+      for (int k = 0; k < V; k++) dA[0][k] = e[k + 2] - e[k];
+      load_stencil_row<V, XCH>(bsr - P, j, jl, jr, lane, e);
+#pragma unroll
+      for (int k = 0; k < V; k++) dB[0][k] = e[k + 2] - e[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; k++) { dA[0][k] = 0.0f; dB[0][k] = 0.0f; }
+    }
+    load_stencil_row<V, XCH>(asr, j, jl, jr, lane, e);
+#pragma unroll
+    for (int k = 0; k < V; k++) dA[1][k] = e[k + 2] - e[k];
+    load_stencil_row<V, XCH>(bsr, j, jl, jr, lane, e);
+#pragma unroll
+    for (int k = 0; k < V; k++) dB[1][k] = e[k + 2] - e[k];
+  }
+
+  auto row_update = [&](int n, float (&dAq)[V], float (&dBq)[V]) {
+    // on entry dAq/dBq hold row n-1; on exit row n+1
+    float ea[V + 2], eb[V + 2], a0v[V], ac[V], bc[V], an[V], bn[V];
+    load_stencil_row<V, XCH>(asr + P, j, jl, jr, lane, ea);
+    load_stencil_row<V, XCH>(bsr + P, j, jl, jr, lane, eb);
+    load_v<V>(a0r, a0v);
+    load_v<V>(acr, ac);
+    load_v<V>(bcr, bc);
+    const float fn = (float)n;
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      point_update(p, n, fn, mu_part[k], mu1_part[k], a0v[k], ac[k], bc[k],
+                   ea[k + 2], ea[k], eb[k + 2], eb[k], dAq[k], dBq[k], an[k], bn[k]);
+      dAq[k] = ea[k + 2] - ea[k];
+      dBq[k] = eb[k + 2] - eb[k];
+    }
+    if (wr_all) {
+      store_v<V>(aor, an);
+      if (n > 0) store_v<V>(bor, bn);
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; k++) {
+        if (wr[k]) {
+          aor[k] = an[k];
+          if (n > 0) bor[k] = bn[k];
+        }
+      }
+    }
+    a0r += P; acr += P; bcr += P; aor += P; bor += P; asr += P; bsr += P;
+  };
+
+  int n = n0;
+  for (; n + 1 < n1; n += 2) {
+    row_update(n,     dA[0], dB[0]);
+    row_update(n + 1, dA[1], dB[1]);
+  }
+  if (n < n1) row_update(n, dA[0], dB[0]);
+}
+
+// ---------------------------------------------------------------------------
+// halo movers: one column of rows 0..nrows-1 of two arrays <-> contiguous buffer
+// ---------------------------------------------------------------------------
+__global__ void halo_pack_kernel(const float *a, const float *b, int pitch, int nrows, int col, float *buf)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * nrows) return;
+  const float *src = i < nrows ? a : b;
+  const int r = i < nrows ? i : i - nrows;
+  buf[i] = src[(size_t)r * pitch + col];
+}
+__global__ void halo_unpack_kernel(float *a, float *b, int pitch, int nrows, int col, const float *buf)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * nrows) return;
+  float *dst = i < nrows ? a : b;
+  const int r = i < nrows ? i : i - nrows;
+  dst[(size_t)r * pitch + col] = buf[i];
+}
+
+// ---------------------------------------------------------------------------
+// reductions (reference: src/boltzmann_c_solver.c:413-437)
+// ---------------------------------------------------------------------------
+struct AvArgs {
+  const float *a, *b;
+  int pitch, m_offset, j_first, j_last;
+  float dPhi, PhiYmin;
+};
+
+// term q of column j: 0: b[1][j]*dPhi   1: a[0][j]*phi_y*dPhi   2: a[1][j]*dPhi
+__device__ __forceinline__ float av_term(const AvArgs &p, int q, int j)
+{
+  if (q == 0) return p.b[(size_t)p.pitch + j] * p.dPhi;
+  if (q == 2) return p.a[(size_t)p.pitch + j] * p.dPhi;
+  const float phi = p.PhiYmin + p.dPhi * (float)(p.m_offset + j - 1);
+  return p.a[j] * phi * p.dPhi;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// tree mode, stage 1: per-block partial sums in double -> ws[block*3 + q]
+__global__ void __launch_bounds__(256) av_partial_kernel(const AvArgs p, double *ws)
+{
+  __shared__ double red[3][4];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int j = p.j_first + blockIdx.x * blockDim.x + threadIdx.x; j <= p.j_last;
+       j += gridDim.x * blockDim.x) {
+    s0 += (double)av_term(p, 0, j);
+    s1 += (double)av_term(p, 1, j);
+    s2 += (double)av_term(p, 2, j);
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = s0; red[1][w] = s1; red[2][w] = s2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int q = threadIdx.x;
+    ws[blockIdx.x * 3 + q] = ((red[q][0] + red[q][1]) + red[q][2]) + red[q][3];
+  }
+}
+
+// tree mode, stage 2: fixed-order sum of the block partials -> sums[0..2]
+__global__ void __launch_bounds__(64) av_combine_kernel(const double *ws, int nblocks, double *sums)
+{
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nblocks; i += 64) {
+    s[0] += ws[i * 3 + 0]; s[1] += ws[i * 3 + 1]; s[2] += ws[i * 3 + 2];
+  }
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const double t = wave_sum(s[q]);
+    if (threadIdx.x == 0) sums[q] = t;
+  }
+}
+
+// the running-average update of av_data[0..5]; cos_wt / sin_wt are
+// cos((double)(omega*t)), sin(...) evaluated by the host's libm so that the
+// values are the ones the CPU solver uses
+__device__ __forceinline__ void av_apply(float *av_data, float v_dr, float v_y, float mmx,
+                                         double cos_wt, double sin_wt, float dt)
+{
+  const int av_count = (int)(av_data[0] + 1.0f);
+  av_data[1] += (v_dr - av_data[1]) / (float)av_count;
+  av_data[2] += (v_y  - av_data[2]) / (float)av_count;
+  av_data[3] += (mmx  - av_data[3]) / (float)av_count;
+  av_data[4] = (float)((double)av_data[4] + cos_wt * (double)v_dr * (double)dt);
+  av_data[5] = (float)((double)av_data[5] + sin_wt * (double)v_dr * (double)dt);
+  av_data[0] += 1.0f;
+}
+
+__global__ void av_update_kernel(const double *sums, float *av_data, double cos_wt, double sin_wt, float dt)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    av_apply(av_data, (float)sums[0], (float)sums[1], (float)sums[2], cos_wt, sin_wt, dt);
+}
+
+// exact mode: wave q (q = 0,1,2) forms sum q by adding the terms one at a time
+// in float in column order, which is the reference's order of operations.
+// Lanes compute 64 terms in parallel; the additions run down the lanes.
+__global__ void __launch_bounds__(192) av_exact_kernel(const AvArgs p, float *av_data,
+                                                       double cos_wt, double sin_wt, float dt)
+{
+  __shared__ float tot[3];
+  const int q    = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  float acc = 0.0f;
+  int base = p.j_first;
+  float term = (base + lane <= p.j_last) ? av_term(p, q, base + lane) : 0.0f;
+  while (base <= p.j_last) {
+    const int nb = base + 64;
+    // fetch the next 64 terms while this batch is being added
+    const float next = (nb + lane <= p.j_last) ? av_term(p, q, nb + lane) : 0.0f;
+    const int valid = p.j_last - base + 1;
+    if (valid >= 64) {
+#pragma unroll
+      for (int k = 0; k < 64; k++)
+        acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, term), k));
+    } else {
+      for (int k = 0; k < valid; k++)
+        acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, term), k));
+    }
+    term = next;
+    base = nb;
+  }
+  if (lane == 0) tot[q] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) av_apply(av_data, tot[0], tot[1], tot[2], cos_wt, sin_wt, dt);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+int ensure_workspace()
+{
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (g_ws && g_ws_device == dev) return 0;
+  e = hipMalloc((void **)&g_ws, sizeof(double) * (kMaxAvBlocks * 3 + 4));
+  if (e != hipSuccess) { g_ws = nullptr; return (int)e; }
+  g_ws_device = dev;
+  return 0;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int V, int XCH>
+int launch_sweep(const SweepArgs &args, int block)
+{
+  const int cols   = args.j_last + 1;                     // columns 0..j_last get a lane
+  const int lanes  = (cols + V - 1) / V;
+  dim3 grid((lanes + block - 1) / block, (args.N + args.n_chunk - 1) / args.n_chunk);
+  hipLaunchKernelGGL((sweep_kernel<V, XCH>), grid, dim3(block), 0, g_stream, args);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C boundary
+// ---------------------------------------------------------------------------
+extern "C" {
+
+void HandleError(int err, const char *file, int line)
+{
+  if (err != (int)hipSuccess) {
+    printf("%s in %s at line %d\n", hipGetErrorString((hipError_t)err), file, line);
+    exit(EXIT_FAILURE);
+  }
+}
+
+void load_data(void)
+{
+  g_phys.E_dc = host_E_dc;       g_phys.E_omega = host_E_omega;  g_phys.omega = host_omega;
+  g_phys.B = host_B;             g_phys.dt = host_dt;            g_phys.dPhi = host_dPhi;
+  g_phys.PhiYmin = PhiYmin;      g_phys.nu = host_nu;            g_phys.nu2 = host_nu2;
+  g_phys.nu_tilde = host_nu_tilde; g_phys.bdt = host_bdt;
+  g_phys.N = host_N;             g_phys.M = host_M;
+  g_phys.pitch = PADDED_MSIZE;   g_phys.TMSIZE = host_TMSIZE;
+  g_phys.loaded = true;
+}
+
+void slb_set_stream(void *s)           { g_stream = (hipStream_t)s; }
+void *slb_get_stream(void)             { return (void *)g_stream; }
+void slb_set_av_mode(int mode)         { g_av_mode = (mode == SLB_AV_TREE) ? SLB_AV_TREE : SLB_AV_EXACT; }
+void slb_set_tuning(int v, int nc, int b) { g_variant = v; g_n_chunk = nc; g_block = b; }
+const char *slb_version(void)          { return "slb2d-gfx950 0.1"; }
+
+int slb_sweep(const slb_slab *slab,
+              const float *a0, const float *a_centre, const float *b_centre,
+              const float *a_stencil, const float *b_stencil,
+              float *a_out, float *b_out,
+              float cos_omega_t, float cos_omega_t_plus_dt)
+{
+  if (!g_phys.loaded) { fprintf(stderr, "slb_sweep: load_data() has not been called\n"); return -1; }
+  if (!slab || slab->pitch < 3 || slab->j_first < 1 || slab->j_last > slab->pitch - 2 ||
+      g_phys.N < 1) {
+    fprintf(stderr, "slb_sweep: bad geometry (pitch=%d j_first=%d j_last=%d N=%d)\n",
+            slab ? slab->pitch : -1, slab ? slab->j_first : -1, slab ? slab->j_last : -1, g_phys.N);
+    return -1;
+  }
+  if (slab->j_last < slab->j_first) return 0;   // empty slab: nothing to update
+
+  SweepArgs s;
+  s.a0 = a0; s.a_c = a_centre; s.b_c = b_centre; s.a_s = a_stencil; s.b_s = b_stencil;
+  s.a_out = a_out; s.b_out = b_out;
+  s.E_dc = g_phys.E_dc; s.E_omega = g_phys.E_omega; s.B = g_phys.B; s.dt = g_phys.dt;
+  s.dPhi = g_phys.dPhi; s.PhiYmin = g_phys.PhiYmin; s.nu = g_phys.nu; s.nu2 = g_phys.nu2;
+  s.nu_tilde = g_phys.nu_tilde; s.bdt = g_phys.bdt;
+  s.cos_t = cos_omega_t; s.cos_t1 = cos_omega_t_plus_dt;
+  s.N = g_phys.N; s.pitch = slab->pitch;
+  s.j_first = slab->j_first; s.j_last = slab->j_last; s.m_offset = slab->m_offset;
+
+  const bool can_vec = (slab->pitch % 4 == 0) && aligned16(a0) && aligned16(a_centre) &&
+                       aligned16(b_centre) && aligned16(a_stencil) && aligned16(b_stencil) &&
+                       aligned16(a_out) && aligned16(b_out);
+  int variant = g_variant;
+  if (variant == 0) variant = can_vec ? 3 : 1;
+  if (variant != 1 && !can_vec) {
+    fprintf(stderr, "slb_sweep: variant %d needs a row pitch that is a multiple of 4 floats and 16-byte aligned arrays\n", variant);
+    return -1;
+  }
+  const int block = g_block > 0 ? g_block : 256;
+  if (block % 64 != 0 || block > 256) { fprintf(stderr, "slb_sweep: block must be 64, 128, 192 or 256\n"); return -1; }
+
+  // rows per workgroup: whole N when the columns alone fill the chip, else split
+  // n so that about 16 waves per CU exist; each split re-reads two stencil rows
+  int n_chunk = g_n_chunk;
+  if (n_chunk <= 0) {
+    const int  V      = variant == 1 ? 1 : 4;
+    const long waves  = ((long)(slab->j_last + 1) / V + 63) / 64;
+    const long target = 256L * 16L;
+    long split = waves >= target ? 1 : (target + waves - 1) / waves;
+    n_chunk = (int)((s.N + split - 1) / split);
+    if (n_chunk < 8) n_chunk = 8;
+    if (n_chunk > s.N) n_chunk = s.N;
+  }
+  s.n_chunk = n_chunk;
+
+  switch (variant) {
+    case 1:  return launch_sweep<1, 0>(s, block);
+    case 2:  return launch_sweep<4, 0>(s, block);
+    case 3:  return launch_sweep<4, 1>(s, block);
+    default:
+      fprintf(stderr, "slb_sweep: unknown variant %d\n", variant);
+      return -1;
+  }
+}
+
+void step_on_grid(int blocks, float *a0, float *a_current, float *b_current,
+                  float *a_next, float *b_next,
+                  float *a_current_hs, float *b_current_hs,
+                  float t, float t_hs, float cos_omega_t, float cos_omega_t_plus_dt)
+{
+  (void)blocks; (void)t; (void)t_hs;
+  const slb_slab slab = {g_phys.pitch, 0, 1, g_phys.TMSIZE};
+  int rc = slb_sweep(&slab, a0, a_current, b_current, a_current_hs, b_current_hs,
+                     a_next, b_next, cos_omega_t, cos_omega_t_plus_dt);
+  if (rc > 0) HandleError(rc, __FILE__, __LINE__);
+  if (rc < 0) exit(EXIT_FAILURE);
+}
+
+void step_on_half_grid(int blocks, float *a0, float *a_current, float *b_current,
+                       float *a_next, float *b_next,
+                       float *a_current_hs, float *b_current_hs,
+                       float *a_next_hs, float *b_next_hs,
+                       float t, float t_hs, float cos_omega_t, float cos_omega_t_plus_dt)
+{
+  (void)blocks; (void)t; (void)t_hs; (void)a_current; (void)b_current;
+  const slb_slab slab = {g_phys.pitch, 0, 1, g_phys.TMSIZE - 1};
+  int rc = slb_sweep(&slab, a0, a_current_hs, b_current_hs, a_next, b_next,
+                     a_next_hs, b_next_hs, cos_omega_t, cos_omega_t_plus_dt);
+  if (rc > 0) HandleError(rc, __FILE__, __LINE__);
+  if (rc < 0) exit(EXIT_FAILURE);
+}
+
+int slb_halo_pack(const float *a, const float *b, int pitch, int nrows, int col, float *buf)
+{
+  if (nrows < 1 || col < 0 || col >= pitch) return -1;
+  const int n = 2 * nrows;
+  hipLaunchKernelGGL(halo_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, a, b, pitch, nrows, col, buf);
+  return (int)hipGetLastError();
+}
+
+int slb_halo_unpack(float *a, float *b, int pitch, int nrows, int col, const float *buf)
+{
+  if (nrows < 1 || col < 0 || col >= pitch) return -1;
+  const int n = 2 * nrows;
+  hipLaunchKernelGGL(halo_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, a, b, pitch, nrows, col, buf);
+  return (int)hipGetLastError();
+}
+
+static AvArgs make_av_args(const slb_slab *slab, const float *a, const float *b)
+{
+  AvArgs p;
+  p.a = a; p.b = b; p.pitch = slab->pitch; p.m_offset = slab->m_offset;
+  p.j_first = slab->j_first; p.j_last = slab->j_last;
+  p.dPhi = g_phys.dPhi; p.PhiYmin = g_phys.PhiYmin;
+  return p;
+}
+
+int slb_av_partial(const slb_slab *slab, const float *a, const float *b, double *sums)
+{
+  if (!g_phys.loaded || !slab || slab->j_first < 0 || slab->j_last >= slab->pitch) return -1;
+  int rc = ensure_workspace();
+  if (rc) return rc;
+  const AvArgs p = make_av_args(slab, a, b);
+  const int cols = slab->j_last - slab->j_first + 1;
+  int nb = cols > 0 ? (cols + 256 * 8 - 1) / (256 * 8) : 1;
+  if (nb > kMaxAvBlocks) nb = kMaxAvBlocks;
+  hipLaunchKernelGGL(av_partial_kernel, dim3(nb), dim3(256), 0, g_stream, p, g_ws);
+  hipLaunchKernelGGL(av_combine_kernel, dim3(1), dim3(64), 0, g_stream, (const double *)g_ws, nb, sums);
+  return (int)hipGetLastError();
+}
+
+int slb_av_update(const double *sums, float *av_data, float t)
+{
+  if (!g_phys.loaded) return -1;
+  const float wt = g_phys.omega * t;            // float product, as the reference forms it
+  hipLaunchKernelGGL(av_update_kernel, dim3(1), dim3(64), 0, g_stream, sums, av_data,
+                     cos((double)wt), sin((double)wt), g_phys.dt);
+  return (int)hipGetLastError();
+}
+
+void av(int blocks, float *a, float *b, float *av_data, float t)
+{
+  (void)blocks;
+  // columns 1..M, i.e. m < TMSIZE (reference: src/boltzmann_c_solver.c:417)
+  const slb_slab slab = {g_phys.pitch, 0, 1, g_phys.TMSIZE - 1};
+  int rc;
+  if (g_av_mode == SLB_AV_TREE) {
+    rc = ensure_workspace();
+    if (rc == 0) rc = slb_av_partial(&slab, a, b, g_ws + kMaxAvBlocks * 3);
+    if (rc == 0) rc = slb_av_update(g_ws + kMaxAvBlocks * 3, av_data, t);
+  } else {
+    const AvArgs p = make_av_args(&slab, a, b);
+    const float wt = g_phys.omega * t;
+    hipLaunchKernelGGL(av_exact_kernel, dim3(1), dim3(192), 0, g_stream, p, av_data,
+                       cos((double)wt), sin((double)wt), g_phys.dt);
+    rc = (int)hipGetLastError();
+  }
+  if (rc > 0) HandleError(rc, __FILE__, __LINE__);
+  if (rc < 0) exit(EXIT_FAILURE);
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+/*
+ * slb_host.h -- host side of the solver: command line, derived constants,
+ * initial state, time loop and the display=4/8/77 reductions.  Mirrors the
+ * reference's host program (reference: src/boltzmann_solver.c,
+ * src/boltzmann_cli.c) on top of the boundary in include/slb_abi.h.
+ */
+#ifndef SLB_HOST_H
+#define SLB_HOST_H
+
+#include <stdio.h>
+#include "../../include/slb_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* the reference's PI literal (src/constants.h:11): the double nearest pi */
+#define SLB_PI 3.141592653589793115998
+
+/* command-line state (reference: src/boltzmann_cli.c:20-64) */
+extern int   quiet, display, device;
+extern float frame_start, t_max;
+extern char *out_file;
+extern FILE *out, *read_from;
+
+/* reference: src/boltzmann_cli.c:93-189 and :70-91 */
+void  parse_cmd(int argc, char **argv);
+float scan_for_new_parameters(void);
+
+/* Modified Bessel function I_n(x), integer n (the reference calls GSL:
+ * src/boltzmann_solver.c:122, 359-360, 426-427). */
+double slb_bessel_In(int n, double x);
+
+/* host_dPhi, NSIZE, MSIZE, PADDED_MSIZE, MP1, host_TMSIZE, host_nu, host_nu2,
+ * host_nu_tilde, host_bdt from the command-line values, then load_data()
+ * (reference: src/boltzmann_solver.c:97-117). */
+void slb_derive_and_load(void);
+
+/* ---- solver object: device arrays + ping-pong indices + loop time ------- */
+typedef struct slb_solver {
+  int   N, M;            /* global n-harmonics, g-grid                           */
+  int   rank, nranks;    /* phi_y slab index / count                             */
+  int   W;               /* columns this slab owns on the half-step lattice      */
+  int   pitch;           /* floats per row of every device array                 */
+  int   m_offset;        /* global column of local column 0                      */
+  slb_slab main_slab, half_slab, av_slab;
+  float *a0, *a[4], *b[4];   /* device */
+  float *av_data;            /* device, 6 floats */
+  double *sums;              /* device, 4 doubles */
+  float *halo_buf;           /* device, 4 x 2*(N+1) floats: send L, send R, recv L, recv R */
+  int   current, next, current_hs, next_hs;
+  float t, frame_time;
+  long  steps;
+} slb_solver;
+
+/* Allocate the slab of rank `rank` of `nranks`, build a0 for its columns
+ * (ghost columns included), a[0] <- a0, everything else zero
+ * (reference: src/boltzmann_solver.c:119-153).  Uses the host_* globals;
+ * call slb_derive_and_load() first.  Returns NULL after printing the reason. */
+slb_solver *slb_solver_create(int rank, int nranks);
+void        slb_solver_destroy(slb_solver *s);
+
+/* the tiptoe half step (reference: src/boltzmann_solver.c:158-165) */
+void slb_solver_tiptoe(slb_solver *s);
+
+/* the two sweeps at the solver's own ping-pong position, and the swap */
+void slb_solver_sweep_main(slb_solver *s, float cos_omega_t, float cos_omega_t_plus_dt);
+void slb_solver_sweep_half(slb_solver *s, float cos_omega_t, float cos_omega_t_plus_dt);
+void slb_solver_swap(slb_solver *s);
+
+/* cosines of one loop iteration at time t, formed as the reference forms them
+ * (reference: src/boltzmann_solver.c:204-214): c[0..1] main sweep, c[2..3] half */
+void slb_step_cosines(float t, float c[4]);
+
+/* one loop iteration without display work, single slab (no halo exchange) */
+void slb_solver_step(slb_solver *s);
+
+/* `steps` iterations bracketed by HIP events on the launch stream; *ms gets the
+ * elapsed device time.  Single slab. */
+int slb_solver_run_timed(slb_solver *s, int steps, float *ms);
+
+/* halo columns of the arrays the NEXT sweep reads as stencil.
+ * which: 0 = before the main sweep (the half-step lattice: a/b[current_hs]),
+ *        1 = before the half sweep (the lattice just written: a/b[next]).
+ * side:  0 = left neighbour (send my column 1, receive into column 0),
+ *        1 = right neighbour (send my column W, receive into column W+1).
+ * buf holds 2*(N+1) floats (device). */
+int slb_solver_halo_pack  (slb_solver *s, int which, int side, float *buf);
+int slb_solver_halo_unpack(slb_solver *s, int which, int side, const float *buf);
+
+/* copy rows [row0, row0+nrows) of device array `arr` (0 = a0, 1..4 = a[0..3],
+ * 5..8 = b[0..3]) into dst as nrows x pitch floats */
+int slb_solver_get_rows(slb_solver *s, int arr, int row0, int nrows, float *dst);
+
+/* ---- display reductions on host rows (single slab) ----------------------
+ * rows are passed with the DEVICE pitch; the sums index them the way the CPU
+ * solver indexes its unpadded arrays, including its flat-index overrun. */
+float slb_host_norm(const float *a_row0, int M, float dPhi, float alpha);
+
+/* display=4 sums over m=1..M-1 (reference: src/boltzmann_solver.c:350-364) */
+void slb_host_display4_sums(const float *a_rows01, const float *b_row1, int pitch,
+                            float out3[3]);
+/* display=77 sums over the CPU solver's flat index 1..2M+1
+ * (reference: src/boltzmann_c_solver.c:303-317); a_rows: rows 0..2 of a,
+ * b_rows12: rows 1..2 of b */
+void slb_host_display77_sums(const float *a_rows012, const float *b_rows12, int pitch,
+                             float out3[3]);
+void slb_host_multipliers(float k3[3]);
+
+/* the whole program behind main() */
+int slb_main(int argc, char **argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,212 @@
+/*
+ * slb_main.c -- the boltzmann_solver program: same command line and the same
+ * display=4 / display=8 / display=77 outputs as the reference, driving the
+ * gfx950 kernels through the boundary in include/slb_abi.h.
+ *
+ * Control flow follows the reference host (reference: src/boltzmann_solver.c:74-401);
+ * where the reference's CUDA host and its CPU solver disagree (column ranges,
+ * which reductions are compounded in place for display=77, the flat-index
+ * sums), the CPU solver is followed, because it is the parity target
+ * (reference: src/boltzmann_c_solver.c:157-331).
+ */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "slb_host.h"
+
+#define HIP_OK(call) HandleError((int)(call), __FILE__, __LINE__)
+
+static const char *HDR4 =
+  "#E_{dc}                \\tilde{E}_{\\omega}     \\tilde{\\omega}         mu                     "
+  "v_{dr}/v_{p}         A(\\omega)              NORM     v_{y}/v_{p}    m/m_{x,k}   "
+  "<v_{dr}/v_{p}>   <v_{y}/v_{p}>    <m/m_{x,k}>    Asin\n";
+static const char *HDR77 =
+  "#E_{dc}                \\tilde{E}_{\\omega}     \\tilde{\\omega}         mu                     "
+  "v_{dr}/v_{p}         A(\\omega)              NORM     v_{y}/v_{p}    m/m_{x,k}   "
+  "<v_{dr}/v_{p}>   <v_{y}/v_{p}>    <m/m_{x,k}>  A_{inst}  t    Asin\n";
+
+/* the in-place rescaling both outputs apply to the averaging data
+ * (reference: src/boltzmann_c_solver.c:254-260, 319-325) */
+static void scale_av(float *av6, const float k3[3], float period)
+{
+  av6[1] *= k3[0];
+  av6[2] *= k3[1];
+  av6[3] *= k3[2];
+  av6[4] *= k3[0]; av6[4] /= period;
+  av6[5] *= k3[0]; av6[5] /= period;
+}
+
+/* one display=77 record (reference: src/boltzmann_c_solver.c:298-331) */
+static void write_frame77(float norm, const float *a012, const float *b12, int pitch,
+                          float *av6, float t)
+{
+  printf("\n# t=%0.20f norm=%0.20f\n", t, norm);
+  float s3[3], k3[3];
+  slb_host_display77_sums(a012, b12, pitch, s3);
+  slb_host_multipliers(k3);
+  s3[0] *= k3[0]; s3[1] *= k3[1]; s3[2] *= k3[2];
+  scale_av(av6, k3, t);
+  fputs(HDR77, out);
+  fprintf(out, "%0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f\n",
+          host_E_dc, host_E_omega, host_omega, host_mu, s3[0], av6[4], norm, s3[1],
+          s3[2], av6[1], av6[2], av6[3], cos(host_omega * t) * s3[0], t, av6[4]);
+}
+
+/* the display=4 record (reference: src/boltzmann_solver.c:348-380) */
+static void write_display4(float norm, const float *a01, const float *b1, int pitch,
+                           float *av6, float T)
+{
+  if (quiet == 0) printf("\n# norm=%0.20f\n", norm);
+  float s3[3], k3[3];
+  slb_host_display4_sums(a01, b1, pitch, s3);
+  slb_host_multipliers(k3);
+  s3[0] *= k3[0]; s3[1] *= k3[1]; s3[2] *= k3[2];
+  scale_av(av6, k3, T);
+  fprintf(out, "# display=%d E_dc=%0.20f E_omega=%0.20f omega=%0.20f mu=%0.20f alpha=%0.20f n-harmonics=%d PhiYmin=%0.20f PhiYmax=%0.20f B=%0.20f t-max=%0.20f dt=%0.20f g-grid=%d\n",
+          display, host_E_dc, host_E_omega, host_omega, host_mu, host_alpha, host_N,
+          PhiYmin, PhiYmax, host_B, t_start, host_dt, host_M);
+  fputs(HDR4, out);
+  fprintf(out, "%0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f %0.20f\n",
+          host_E_dc, host_E_omega, host_omega, host_mu, s3[0], av6[4], norm, s3[1],
+          s3[2], av6[1], av6[2], av6[3], av6[5]);
+}
+
+/* display=8: f(phi_x, phi_y) = max(0, sum_n a_n cos(n phi_x) + b_n sin(n phi_x))
+ * on 629 phi_x values x columns 1..M+1 (reference: src/boltzmann_solver.c:487-507).
+ * cos(n*phi_x) and sin(n*phi_x) do not depend on the column, so they are formed
+ * once per phi_x; each output value goes through the same operations as in
+ * the reference loop.  The closing norm uses the unpadded (CPU) row pitch for
+ * its flat-index sum, so it does not depend on how device rows are padded. */
+static void write_frame8(FILE *f, const float *a, const float *b, int pitch, float t)
+{
+  const int cpu_pitch = host_M + 3;
+  fprintf(f, "# t=%0.20f\n", t);
+  float norm = 0;
+  for (int m = 1; m < 2 * host_M + 2; m++) {
+    const int r = m >= cpu_pitch ? 1 : 0;
+    norm += a[(size_t)r * pitch + (m - r * cpu_pitch)] * host_dPhi;
+  }
+  norm *= 2 * SLB_PI * sqrt(host_alpha);
+
+  double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)(host_N + 1));
+  for (float phi_x = -SLB_PI; phi_x < SLB_PI; phi_x += 0.01) {
+    for (int n = 0; n < host_N + 1; n++) {
+      cs[2 * n]     = cos(n * phi_x);
+      cs[2 * n + 1] = sin(n * phi_x);
+    }
+    for (int m = 1; m < host_M + 2; m++) {
+      float value = 0;
+      for (int n = 0; n < host_N + 1; n++)
+        value += a[(size_t)n * pitch + m] * cs[2 * n] + b[(size_t)n * pitch + m] * cs[2 * n + 1];
+      fprintf(f, "%0.5f %0.5f %0.20f\n", phi_x, PhiYmin + host_dPhi * (m - 1), value < 0 ? 0 : value);
+    }
+  }
+  free(cs);
+  fprintf(f, "# norm=%0.20f\n", norm);
+  printf("# norm=%0.20f\n", norm);
+}
+
+int slb_main(int argc, char **argv)
+{
+  parse_cmd(argc, argv);
+  if (display == 3 || display == 7 || display == 9) {
+    fprintf(stderr, "ERROR: display=%d is not available in this build; use display=4, 8 or 77.\n", display);
+    return EXIT_FAILURE;
+  }
+  HIP_OK(hipSetDevice(device));
+
+  float T = host_omega > 0 ? (2 * SLB_PI / host_omega) : 0;   /* period of the a/c field */
+  t_max = t_start + T;
+  if (quiet == 0) printf("# t_max = %0.20f\n", t_max);
+
+  slb_derive_and_load();
+  slb_solver *s = slb_solver_create(0, 1);
+  if (!s) return EXIT_FAILURE;
+  slb_solver_tiptoe(s);
+
+  const int pitch = s->pitch;
+  float *a_rows = (float *)malloc(sizeof(float) * 3 * (size_t)pitch);
+  float *b_rows = (float *)malloc(sizeof(float) * 3 * (size_t)pitch);
+  float av6[6] = {0, 0, 0, 0, 0, 0};
+
+  int   progress = 0;
+  float frame_time = 0;
+  float t0 = 0, t = 0;
+
+  for (;;) {
+    for (t = t0; t < t_max; t += host_dt) {
+      float c[4];
+      slb_step_cosines(t, c);
+      slb_solver_sweep_main(s, c[0], c[1]);
+      slb_solver_sweep_half(s, c[2], c[3]);
+
+      if (host_E_omega > 0 && display == 77 && frame_time >= 0.01) {
+        av(0, s->a[s->next], s->b[s->next], s->av_data, t);
+        slb_solver_get_rows(s, 1 + s->current, 0, 3, a_rows);
+        slb_solver_get_rows(s, 5 + s->current, 1, 2, b_rows);
+        HIP_OK(hipMemcpy(av6, s->av_data, sizeof(av6), hipMemcpyDeviceToHost));
+        const float norm = slb_host_norm(a_rows, host_M, host_dPhi, host_alpha);
+        write_frame77(norm, a_rows, b_rows, pitch, av6, t);
+        /* the CPU solver rescales its averaging data in place at every record */
+        HIP_OK(hipMemcpy(s->av_data, av6, sizeof(av6), hipMemcpyHostToDevice));
+        frame_time = 0;
+      }
+      if (host_E_omega > 0 && display != 7 && display != 77 && display != 8 && t >= t_start)
+        av(0, s->a[s->next], s->b[s->next], s->av_data, t);
+
+      slb_solver_swap(s);
+
+      if (out != stdout && quiet == 0) {
+        if (++progress == 300) {
+          printf("\rt=%0.9f %0.2f%%", t, t / t_max * 100);
+          fflush(stdout);
+          progress = 0;
+        }
+      }
+      frame_time += host_dt;
+    }
+
+    slb_solver_get_rows(s, 1 + s->current, 0, 2, a_rows);
+    slb_solver_get_rows(s, 5 + s->current, 1, 1, b_rows);
+    HIP_OK(hipMemcpy(av6, s->av_data, sizeof(av6), hipMemcpyDeviceToHost));
+    const float norm = slb_host_norm(a_rows, host_M, host_dPhi, host_alpha);
+
+    if (display == 8) {
+      const size_t cells = (size_t)(host_N + 1) * pitch;
+      float *fa = (float *)malloc(sizeof(float) * cells), *fb = (float *)malloc(sizeof(float) * cells);
+      slb_solver_get_rows(s, 1 + s->current, 0, host_N + 1, fa);
+      slb_solver_get_rows(s, 5 + s->current, 0, host_N + 1, fb);
+      FILE *f = fopen("frame.data", "w");
+      if (!f) { perror("ERROR"); return EXIT_FAILURE; }
+      printf("\nWriting frame %s\n", "frame.data");
+      write_frame8(f, fa, fb, pitch, t);
+      fclose(f);
+      free(fa); free(fb);
+      break;
+    }
+    if (display == 4) write_display4(norm, a_rows, b_rows, pitch, av6, T);
+
+    if (read_from == NULL) break;
+
+    /* new parameter from stdin, continue from the present state
+     * (reference: src/boltzmann_solver.c:384-393) */
+    const float timeout = scan_for_new_parameters();
+    if (timeout < -900) break;
+    t_start = t + timeout;
+    t_max = t_start + T;
+    t0 = t + host_dt;
+    T = host_omega > 0 ? (2 * SLB_PI / host_omega) : 0;
+    /* B enters the sweeps through bdt, so the derived constants are refreshed
+     * as well (the reference re-uploads a stale bdt here) */
+    slb_derive_and_load();
+    HIP_OK(hipMemset(s->av_data, 0, 6 * sizeof(float)));
+    if (quiet == 0) printf("# t_max = %0.20f\n", t_max);
+  }
+
+  if (out != NULL && out != stdout && out != stderr) fclose(out);
+  free(a_rows); free(b_rows);
+  slb_solver_destroy(s);
+  return EXIT_SUCCESS;
+}

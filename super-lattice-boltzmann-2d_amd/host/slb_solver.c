@@ -1,0 +1,268 @@
+/*
+ * slb_solver.c -- host engine of the stepping loop: derived constants, device
+ * arrays, initial state, tiptoe, the two sweeps per iteration with their
+ * ping-pong bookkeeping, halo columns for phi_y slabs, and the host-side
+ * display reductions.  Plays the part of the reference's main() up to and
+ * including its time loop (reference: src/boltzmann_solver.c:97-253), split
+ * into calls so that a single-GPU program, a benchmark and a one-process-per-GPU
+ * driver can all use it.
+ */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "slb_host.h"
+
+#define HIP_OK(call) HandleError((int)(call), __FILE__, __LINE__)
+
+/* reference: src/boltzmann_solver.c:97-117 */
+void slb_derive_and_load(void)
+{
+  host_dPhi = (PhiYmax - PhiYmin) / host_M;
+
+  NSIZE = host_N + 1;
+  MSIZE = host_M + 3;
+  /* rows start on 128-byte boundaries (32 floats) */
+  PADDED_MSIZE = (MSIZE + 31) / 32 * 32;
+  MP1 = host_M + 1;
+  host_TMSIZE = host_M + 1;
+
+  host_nu = 1 + host_dt / 2;
+  host_nu2 = host_nu * host_nu;
+  host_nu_tilde = 1 - host_dt / 2;
+  host_bdt = host_B * host_dt / (4 * host_dPhi);
+
+  load_data();
+}
+
+static float phi_y_of(int m) { return PhiYmin + host_dPhi * (m - 1); }
+
+/* Equilibrium coefficients for global columns m_offset .. m_offset+cols-1
+ * (reference: src/boltzmann_solver.c:119-126).  exp(-mu*phi_y^2/2) depends on
+ * the column only and is evaluated once per column in long double; the
+ * reference's product (float coefficient) x (long double expl) -> float is kept. */
+static void fill_a0(float *h, int pitch, int m_offset, int cols)
+{
+  long double *gauss = (long double *)malloc(sizeof(long double) * (size_t)cols);
+  for (int j = 0; j < cols; j++)
+    gauss[j] = expl(-host_mu * pow(phi_y_of(m_offset + j), 2) / 2);
+  const double i0 = slb_bessel_In(0, host_mu);
+  for (int n = 0; n <= host_N; n++) {
+    const float c = slb_bessel_In(n, host_mu) * (n == 0 ? 0.5 : 1) / (SLB_PI * i0)
+                    * sqrt(host_mu / (2 * SLB_PI * host_alpha));
+    float *row = h + (size_t)n * pitch;
+    for (int j = 0; j < cols; j++) row[j] = c * gauss[j];
+  }
+  free(gauss);
+}
+
+slb_solver *slb_solver_create(int rank, int nranks)
+{
+  if (nranks < 1 || rank < 0 || rank >= nranks || host_M < nranks || host_N < 1) {
+    fprintf(stderr, "slb_solver_create: bad partition (rank %d of %d, g-grid %d, n-harmonics %d)\n",
+            rank, nranks, host_M, host_N);
+    return NULL;
+  }
+  slb_solver *s = (slb_solver *)calloc(1, sizeof(*s));
+  if (!s) return NULL;
+  s->N = host_N; s->M = host_M; s->rank = rank; s->nranks = nranks;
+
+  /* columns 1..M are dealt out in contiguous runs; the last slab also carries
+   * column M+1 of the main lattice and the boundary column M+2 */
+  const int base = host_M / nranks, rem = host_M % nranks;
+  s->W = base + (rank < rem ? 1 : 0);
+  const int first = 1 + rank * base + (rank < rem ? rank : rem);
+  s->m_offset = first - 1;
+  const int cols = s->W + 3;
+  s->pitch = nranks == 1 ? PADDED_MSIZE : (cols + 31) / 32 * 32;
+
+  const int last = rank == nranks - 1;
+  s->main_slab = (slb_slab){s->pitch, s->m_offset, 1, s->W + (last ? 1 : 0)};
+  s->half_slab = (slb_slab){s->pitch, s->m_offset, 1, s->W};
+  s->av_slab   = (slb_slab){s->pitch, s->m_offset, 1, s->W};
+
+  const size_t cells = (size_t)(s->N + 1) * (size_t)s->pitch;
+  const size_t bytes = cells * sizeof(float);
+  float *h = (float *)calloc(cells, sizeof(float));
+  if (!h) { fprintf(stderr, "slb_solver_create: out of host memory\n"); free(s); return NULL; }
+  fill_a0(h, s->pitch, s->m_offset, cols);
+
+  HIP_OK(hipMalloc((void **)&s->a0, bytes));
+  HIP_OK(hipMemcpy(s->a0, h, bytes, hipMemcpyHostToDevice));
+  free(h);
+  for (int i = 0; i < 4; i++) {
+    HIP_OK(hipMalloc((void **)&s->a[i], bytes));
+    HIP_OK(hipMalloc((void **)&s->b[i], bytes));
+    HIP_OK(hipMemset(s->a[i], 0, bytes));
+    HIP_OK(hipMemset(s->b[i], 0, bytes));
+  }
+  HIP_OK(hipMemcpy(s->a[0], s->a0, bytes, hipMemcpyDeviceToDevice));
+  HIP_OK(hipMalloc((void **)&s->av_data, 6 * sizeof(float)));
+  HIP_OK(hipMemset(s->av_data, 0, 6 * sizeof(float)));
+  HIP_OK(hipMalloc((void **)&s->sums, 4 * sizeof(double)));
+  HIP_OK(hipMalloc((void **)&s->halo_buf, (size_t)8 * (s->N + 1) * sizeof(float)));
+  HIP_OK(hipDeviceSynchronize());
+
+  s->current = 0; s->next = 1; s->current_hs = 2; s->next_hs = 3;
+  s->t = 0; s->frame_time = 0; s->steps = 0;
+  return s;
+}
+
+void slb_solver_destroy(slb_solver *s)
+{
+  if (!s) return;
+  hipFree(s->a0);
+  for (int i = 0; i < 4; i++) { hipFree(s->a[i]); hipFree(s->b[i]); }
+  hipFree(s->av_data); hipFree(s->sums); hipFree(s->halo_buf);
+  free(s);
+}
+
+static void check_sweep(int rc, int line)
+{
+  if (rc > 0) HandleError(rc, __FILE__, line);
+  if (rc < 0) exit(EXIT_FAILURE);
+}
+
+/* centre and stencil are both the t=0 lattice; the result is the first
+ * half-step lattice (reference: src/boltzmann_solver.c:161-165) */
+void slb_solver_tiptoe(slb_solver *s)
+{
+  const float c0 = 1;
+  const float c1 = cos(host_omega * (host_dt));
+  check_sweep(slb_sweep(&s->main_slab, s->a0, s->a[s->current], s->b[s->current],
+                        s->a[s->current], s->b[s->current],
+                        s->a[s->current_hs], s->b[s->current_hs], c0, c1), __LINE__);
+}
+
+void slb_solver_sweep_main(slb_solver *s, float c0, float c1)
+{
+  check_sweep(slb_sweep(&s->main_slab, s->a0, s->a[s->current], s->b[s->current],
+                        s->a[s->current_hs], s->b[s->current_hs],
+                        s->a[s->next], s->b[s->next], c0, c1), __LINE__);
+}
+
+void slb_solver_sweep_half(slb_solver *s, float c0, float c1)
+{
+  check_sweep(slb_sweep(&s->half_slab, s->a0, s->a[s->current_hs], s->b[s->current_hs],
+                        s->a[s->next], s->b[s->next],
+                        s->a[s->next_hs], s->b[s->next_hs], c0, c1), __LINE__);
+}
+
+void slb_solver_swap(slb_solver *s)
+{
+  const int c = s->current, h = s->current_hs;
+  s->current = s->next;       s->next = c;
+  s->current_hs = s->next_hs; s->next_hs = h;
+}
+
+/* float products and sums, double cos, float results
+ * (reference: src/boltzmann_solver.c:204-214) */
+void slb_step_cosines(float t, float c[4])
+{
+  const float t_hs = t + host_dt / 2;
+  c[0] = cos(host_omega * t);
+  c[1] = cos(host_omega * (t + host_dt));
+  c[2] = cos(host_omega * t_hs);
+  c[3] = cos(host_omega * (t_hs + host_dt));
+}
+
+void slb_solver_step(slb_solver *s)
+{
+  float c[4];
+  slb_step_cosines(s->t, c);
+  slb_solver_sweep_main(s, c[0], c[1]);
+  slb_solver_sweep_half(s, c[2], c[3]);
+  slb_solver_swap(s);
+  s->t += host_dt;
+  s->frame_time += host_dt;
+  s->steps++;
+}
+
+int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
+{
+  hipStream_t st = (hipStream_t)slb_get_stream();
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0));
+  HIP_OK(hipEventCreate(&e1));
+  HIP_OK(hipEventRecord(e0, st));
+  for (int i = 0; i < steps; i++) slb_solver_step(s);
+  HIP_OK(hipEventRecord(e1, st));
+  HIP_OK(hipEventSynchronize(e1));
+  HIP_OK(hipEventElapsedTime(ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return 0;
+}
+
+int slb_solver_halo_pack(slb_solver *s, int which, int side, float *buf)
+{
+  const int idx = which == 0 ? s->current_hs : s->next;
+  const int col = side == 0 ? 1 : s->W;
+  return slb_halo_pack(s->a[idx], s->b[idx], s->pitch, s->N + 1, col, buf);
+}
+
+int slb_solver_halo_unpack(slb_solver *s, int which, int side, const float *buf)
+{
+  const int idx = which == 0 ? s->current_hs : s->next;
+  const int col = side == 0 ? 0 : s->W + 1;
+  return slb_halo_unpack(s->a[idx], s->b[idx], s->pitch, s->N + 1, col, buf);
+}
+
+int slb_solver_get_rows(slb_solver *s, int arr, int row0, int nrows, float *dst)
+{
+  const float *src = arr == 0 ? s->a0 : (arr <= 4 ? s->a[arr - 1] : s->b[arr - 5]);
+  if (arr < 0 || arr > 8 || row0 < 0 || nrows < 1 || row0 + nrows > s->N + 1) return -1;
+  HIP_OK(hipMemcpy(dst, src + (size_t)row0 * s->pitch, (size_t)nrows * s->pitch * sizeof(float),
+                   hipMemcpyDeviceToHost));
+  return 0;
+}
+
+/* ---- display reductions, evaluated on rows copied to the host ------------ */
+
+/* reference: src/boltzmann_c_solver.c:289-296 */
+float slb_host_norm(const float *a_row0, int M, float dPhi, float alpha)
+{
+  float norm = 0;
+  for (int m = 1; m < M + 1; m++) norm += a_row0[m] * dPhi;
+  norm *= 2 * SLB_PI * sqrt(alpha);
+  return norm;
+}
+
+/* reference: src/boltzmann_solver.c:350-357 */
+void slb_host_display4_sums(const float *a_rows01, const float *b_row1, int pitch, float out3[3])
+{
+  float v_dr = 0, v_y = 0, mmx = 0;
+  for (int m = 1; m < host_M; m++) {
+    v_dr += b_row1[m] * host_dPhi;
+    v_y  += a_rows01[m] * phi_y_of(m) * host_dPhi;
+    mmx  += a_rows01[pitch + m] * host_dPhi;
+  }
+  out3[0] = v_dr; out3[1] = v_y; out3[2] = mmx;
+}
+
+/* The CPU solver sums over its flat index 1..2M+1 with a row pitch of M+3, so
+ * the sums run off the end of the row into the next one, and phi_y keeps
+ * growing with the flat index (reference: src/boltzmann_c_solver.c:303-310).
+ * The same elements are picked out of the padded device rows here. */
+void slb_host_display77_sums(const float *a_rows012, const float *b_rows12, int pitch, float out3[3])
+{
+  const int cpu_pitch = host_M + 3;
+  float v_dr = 0, v_y = 0, mmx = 0;
+  for (int m = 1; m < 2 * host_M + 2; m++) {
+    const int r = m >= cpu_pitch ? 1 : 0, c = m - r * cpu_pitch;
+    v_dr += b_rows12[(size_t)r * pitch + c] * host_dPhi;
+    v_y  += a_rows012[(size_t)r * pitch + c] * phi_y_of(m) * host_dPhi;
+    mmx  += a_rows012[(size_t)(r + 1) * pitch + c] * host_dPhi;
+  }
+  out3[0] = v_dr; out3[1] = v_y; out3[2] = mmx;
+}
+
+/* reference: src/boltzmann_solver.c:359-361 */
+void slb_host_multipliers(float k3[3])
+{
+  const double i0 = slb_bessel_In(0, host_mu), i1 = slb_bessel_In(1, host_mu);
+  k3[0] = 2 * i0 * SLB_PI * sqrt(host_alpha) / i1;
+  k3[1] = 4 * SLB_PI * i0 / i1;
+  k3[2] = SLB_PI * host_alpha * sqrt(host_alpha);
+}

@@ -1,0 +1,86 @@
+"""The C host engine and the boltzmann_solver program vs the CPU oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ARR = {("a0", 0): 0, **{("a", i): 1 + i for i in range(4)}, **{("b", i): 5 + i for i in range(4)}}
+
+
+def _compare_state(sol, orc, M):
+    s = sol.s
+    assert (s.current, s.next, s.current_hs, s.next_hs) == \
+           (orc.st.current, orc.st.next, orc.st.current_hs, orc.st.next_hs)
+    for (which, i), arr in ARR.items():
+        got = sol.rows(arr)[:, :M + 3]
+        exp = orc.array(which, i)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (which, i)
+
+
+@pytest.mark.parametrize("N,M,B,omega,steps", [(32, 4096, 1.0, 1.0, 60), (8, 61, 0.05, 100.0, 25),
+                                               (64, 20001, 0.2, 10.0, 12)])
+def test_engine_fields_bit_exact(slb, oracle, N, M, B, omega, steps):
+    """init (a0, a[0]<-a0), tiptoe and `steps` loop iterations: all nine arrays
+    and the ping-pong indices equal the oracle's, bit for bit."""
+    p = oracle.make_params(N=N, M=M, B=B, omega=omega)
+    slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    orc = oracle.OracleState(p)
+    sol = slb.Solver()
+    try:
+        sol.tiptoe()
+        _compare_state(sol, orc, M)
+        done = 0
+        for chunk in (1, 1, steps - 2):
+            for _ in range(chunk):
+                sol.step()
+            orc.step(chunk)
+            done += chunk
+            _compare_state(sol, orc, M)
+        assert sol.s.t == orc.st.t and sol.s.steps == done
+    finally:
+        sol.close()
+        orc.close()
+
+
+def _run_both(solver_bin, oracle, tmp_path, args, extra_files=()):
+    gdir, odir = tmp_path / "gpu", tmp_path / "orc"
+    gdir.mkdir(), odir.mkdir()
+    g = subprocess.run([solver_bin] + args + ["o=out.txt"], cwd=gdir, capture_output=True, text=True, timeout=600)
+    assert g.returncode == 0, g.stdout + g.stderr
+    o = oracle.run_cli(args + ["o=out.txt"], cwd=odir)
+    return gdir, odir, g, o
+
+
+COMMON = ["E_dc=1", "E_omega=0.1", "mu=5", "alpha=1", "PhiYmin=-4", "PhiYmax=4", "dt=0.001"]
+
+
+def test_program_display4_identical(solver_bin, oracle, tmp_path):
+    args = ["display=4", "omega=100", "B=1", "n-harmonics=32", "g-grid=4096", "t-max=0.05"] + COMMON
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
+    assert (gdir / "out.txt").read_text() == (odir / "out.txt").read_text()
+    assert "# t_max = " in g.stdout and "# norm=" in g.stdout
+
+
+def test_program_display77_identical(solver_bin, oracle, tmp_path):
+    """display=77 trace on a shrunken config-2 shape: every record identical,
+    including the flat-index sums and the in-place rescaling of the averages."""
+    args = ["display=77", "omega=100", "B=0.12", "n-harmonics=64", "g-grid=32768", "t-max=0.05"] + COMMON
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
+    got, exp = (gdir / "out.txt").read_text(), (odir / "out.txt").read_text()
+    assert len(exp.splitlines()) == 22          # 11 records of header + data
+    assert got == exp
+    # the "# t=... norm=..." log lines agree as well
+    pick = lambda s: [l for l in s.splitlines() if l.startswith("# t=")]
+    assert pick(g.stdout) == pick(o.stdout)
+
+
+def test_program_display8_identical(solver_bin, oracle, tmp_path):
+    args = ["display=8", "omega=100", "B=0.5", "n-harmonics=8", "g-grid=61", "t-max=0.01"] + COMMON
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
+    got, exp = (gdir / "frame.data").read_text(), (odir / "frame.data").read_text()
+    assert len(exp.splitlines()) == 629 * 62 + 2
+    assert got == exp
