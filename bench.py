@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Throughput of the Boltzmann stepping loop on MI355X.
+
+One "step" = one iteration of the time loop = main-lattice sweep + half-step
+lattice sweep over the whole (n-harmonics x g-grid) lattice.  The workload is
+BASELINE.json's roofline shape, n-harmonics=128 and g-grid=2^20 PER GPU: at
+--gpus 1 that is config 3; at --gpus 8 the eight phi_y slabs make up config 4
+(g-grid=2^23), so the scaling reported is weak scaling.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints one JSON line (rank 0).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N_HARMONICS = 128
+G_GRID_PER_GPU = 1 << 20
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
+BYTES_PER_POINT_SWEEP = 28     # 5 fp32 reads + 2 fp32 writes per lattice point per sweep
+
+
+def cpu_baseline(n_harm, g_grid, phys, steps):
+    """The CPU oracle (a restatement of the reference's OpenMP solver) on the
+    host cores, same lattice shape, a few steps."""
+    import oracle_binding as ob
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    p = ob.make_params(N=n_harm, M=g_grid, **phys)
+    st = ob.OracleState(p, threads=threads)
+    st.step(1)                                   # touch every page once
+    t0 = time.perf_counter()
+    st.step(steps)
+    dt = time.perf_counter() - t0
+    st.close()
+    return {"value": n_harm * g_grid * steps / dt, "unit": "lattice-point-updates/s",
+            "cores": threads, "kind": "port",
+            "sample": f"{steps} steps of the same n-harmonics={n_harm} g-grid={g_grid} lattice "
+                      f"(OpenMP over phi_y, {threads} threads), after 1 untimed step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n-harmonics", type=int, default=N_HARMONICS)
+    ap.add_argument("--g-grid-per-gpu", type=int, default=G_GRID_PER_GPU)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--n-chunk", type=int, default=0)
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    slb = importlib.import_module("super-lattice-boltzmann-2d_amd")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    torch.zeros(1, device="cuda")              # make this device current for the C library too
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n_harm = args.n_harmonics
+    g_grid = args.g_grid_per_gpu * world
+    phys = dict(E_dc=1.0, E_omega=0.1, omega=100.0, mu=5.0, alpha=1.0, B=4000.0 / g_grid,
+                PhiYmin=-4.0, PhiYmax=4.0, dt=0.001)
+    slb.configure(N=n_harm, M=g_grid, t_start=1.0, **phys)
+    L = slb.lib()
+    L.slb_set_stream(torch.cuda.current_stream().cuda_stream)
+    L.slb_set_tuning(args.variant, args.n_chunk, args.block)
+
+    kernel_ms = None
+    if world == 1:
+        sol = slb.Solver(0, 1)
+        sol.tiptoe()
+        for _ in range(args.warmup):
+            sol.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev_ms = sol.run_timed(args.steps)        # HIP events on the launch stream
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        kernel_ms = ev_ms / (2 * args.steps)     # two sweep launches per step, back to back
+        sol.close()
+    else:
+        import torch.distributed as dist
+        drv = importlib.import_module("super-lattice-boltzmann-2d_amd.dist")
+        run = drv.SlabRun(slb, rank, world)
+        run.tiptoe()
+        for _ in range(args.warmup):
+            run.step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run.step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        w = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+        run.close()
+
+    updates = float(n_harm) * float(g_grid) * args.steps
+    value = updates / wall
+    out = {
+        "metric": "lattice-point-updates/sec (n-harmonics x g-grid per step)",
+        "value": value, "unit": "lattice-point-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (analytic equilibrium initial state, no RNG)",
+        "config": {"workload": f"n-harmonics={n_harm} g-grid={g_grid} "
+                               f"({args.g_grid_per_gpu} columns per GPU, phi_y slabs) "
+                               f"omega=100 B={phys['B']:.6g} dt=0.001, 2 sweeps per step",
+                   "parallelism": f"phi_y-slab x{world}"},
+        "hbm_roofline_frac_per_gpu": 2 * BYTES_PER_POINT_SWEEP * value / world / (HBM_PEAK_GBS * 1e9),
+    }
+    if rank == 0:
+        if kernel_ms is not None:
+            # dominant kernel: sweep_kernel (one launch = one sweep of the whole lattice)
+            points = n_harm * (g_grid + 0.5)      # main sweep M+1 columns, half sweep M
+            achieved = BYTES_PER_POINT_SWEEP * points / (kernel_ms * 1e-3) / 1e9
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tfile):
+                with open(tfile) as f:
+                    tj = json.load(f)
+                if tj.get("n_harmonics") == n_harm and tj.get("g_grid") == g_grid:
+                    traffic = tj.get("bytes_per_launch")
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "kernel": "sweep_kernel", "avg_launch_ms": kernel_ms,
+                               "algorithmic_bytes_per_launch": BYTES_PER_POINT_SWEEP * points}
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(n_harm, g_grid, phys, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Sweep-kernel tuning grid on one GPU: variant x n_chunk x block at a given shape.
+Prints ms per sweep launch and the algorithmic GB/s (28 B per point-sweep)."""
+import argparse
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n-harmonics", type=int, default=128)
+    ap.add_argument("--g-grid", type=int, default=1 << 20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--variants", default="2,3")
+    ap.add_argument("--chunks", default="0,8,16,32,64,128")
+    ap.add_argument("--blocks", default="256,128,64")
+    args = ap.parse_args()
+    import torch
+    slb = importlib.import_module("super-lattice-boltzmann-2d_amd")
+    torch.zeros(1, device="cuda")
+    N, M = args.n_harmonics, args.g_grid
+    slb.configure(N=N, M=M, E_dc=1.0, E_omega=0.1, omega=100.0, mu=5.0, alpha=1.0, B=4000.0 / M,
+                  PhiYmin=-4.0, PhiYmax=4.0, dt=0.001)
+    L = slb.lib()
+    sol = slb.Solver()
+    sol.tiptoe()
+    for v in [int(x) for x in args.variants.split(",")]:
+        for nc in [int(x) for x in args.chunks.split(",")]:
+            for b in [int(x) for x in args.blocks.split(",")]:
+                L.slb_set_tuning(v, nc, b)
+                sol.run_timed(3)
+                ms = min(sol.run_timed(args.steps) for _ in range(3)) / (2 * args.steps)
+                gbs = 28.0 * N * (M + 0.5) / (ms * 1e-3) / 1e9
+                print(f"variant={v} n_chunk={nc:4d} block={b:4d}  {ms:8.4f} ms/sweep  {gbs:8.1f} GB/s  "
+                      f"{gbs / 80.0:5.1f}% of 8 TB/s", flush=True)
+    sol.close()
+
+
+if __name__ == "__main__":
+    main()

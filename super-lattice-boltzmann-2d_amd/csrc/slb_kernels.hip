@@ -43,6 +43,7 @@ struct SweepArgs {
   float *a_out, *b_out;
   float E_dc, E_omega, B, dt, dPhi, PhiYmin, nu, nu2, nu_tilde, bdt, cos_t, cos_t1;
   int N, pitch, j_first, j_last, m_offset, n_chunk;
+  int jj0;          // first column that gets a lane (multiple of V, <= j_first)
 };
 
 // ---------------------------------------------------------------------------
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(256)
 sweep_kernel(const SweepArgs p)
 {
   const int lane = threadIdx.x & 63;
-  const int jj   = (blockIdx.x * blockDim.x + threadIdx.x) * V;   // first own column
+  const int jj   = p.jj0 + (blockIdx.x * blockDim.x + threadIdx.x) * V;   // first own column
   if (XCH == 0 && jj > p.j_last) return;
   // lanes past the end stay alive for the cross-lane exchange; keep their
   // addresses inside the row (pitch is a multiple of V when V > 1)
@@ -371,9 +372,10 @@ int ensure_workspace()
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <int V, int XCH>
-int launch_sweep(const SweepArgs &args, int block)
+int launch_sweep(SweepArgs &args, int block)
 {
-  const int cols   = args.j_last + 1;                     // columns 0..j_last get a lane
+  args.jj0 = args.j_first / V * V;
+  const int cols   = args.j_last + 1 - args.jj0;          // columns jj0..j_last get a lane
   const int lanes  = (cols + V - 1) / V;
   dim3 grid((lanes + block - 1) / block, (args.N + args.n_chunk - 1) / args.n_chunk);
   hipLaunchKernelGGL((sweep_kernel<V, XCH>), grid, dim3(block), 0, g_stream, args);
@@ -441,7 +443,7 @@ int slb_sweep(const slb_slab *slab,
                        aligned16(b_centre) && aligned16(a_stencil) && aligned16(b_stencil) &&
                        aligned16(a_out) && aligned16(b_out);
   int variant = g_variant;
-  if (variant == 0) variant = can_vec ? 3 : 1;
+  if (variant == 0) variant = can_vec ? 2 : 1;
   if (variant != 1 && !can_vec) {
     fprintf(stderr, "slb_sweep: variant %d needs a row pitch that is a multiple of 4 floats and 16-byte aligned arrays\n", variant);
     return -1;
@@ -454,7 +456,7 @@ int slb_sweep(const slb_slab *slab,
   int n_chunk = g_n_chunk;
   if (n_chunk <= 0) {
     const int  V      = variant == 1 ? 1 : 4;
-    const long waves  = ((long)(slab->j_last + 1) / V + 63) / 64;
+    const long waves  = ((long)(slab->j_last - slab->j_first + 1) / V + 63) / 64 + 1;
     const long target = 256L * 16L;
     long split = waves >= target ? 1 : (target + waves - 1) / waves;
     n_chunk = (int)((s.N + split - 1) / split);
