@@ -94,6 +94,9 @@ def lib():
         L.slb_solver_sweep_half.argtypes = [C.POINTER(SolverStruct), f, f]
         L.slb_solver_sweep_half.restype = None
         L.slb_solver_swap.argtypes, L.slb_solver_swap.restype = [C.POINTER(SolverStruct)], None
+        L.slb_solver_sweep_range.argtypes = [C.POINTER(SolverStruct), i, i, i, f, f]
+        L.slb_solver_sweep_range.restype = None
+        L.slb_solver_advance.argtypes, L.slb_solver_advance.restype = [C.POINTER(SolverStruct)], None
         L.slb_step_cosines.argtypes, L.slb_step_cosines.restype = [f, C.POINTER(C.c_float * 4)], None
         L.slb_solver_step.argtypes, L.slb_solver_step.restype = [C.POINTER(SolverStruct)], None
         L.slb_solver_run_timed.argtypes = [C.POINTER(SolverStruct), i, C.POINTER(C.c_float)]
@@ -171,6 +174,12 @@ class Solver:
 
     def swap(self):
         lib().slb_solver_swap(self._p)
+
+    def sweep_range(self, lattice, j_first, j_last, c0, c1):
+        lib().slb_solver_sweep_range(self._p, lattice, j_first, j_last, c0, c1)
+
+    def advance(self):
+        lib().slb_solver_advance(self._p)
 
     def run_timed(self, steps):
         ms = C.c_float(0)

@@ -67,6 +67,12 @@ void slb_solver_tiptoe(slb_solver *s);
 void slb_solver_sweep_main(slb_solver *s, float cos_omega_t, float cos_omega_t_plus_dt);
 void slb_solver_sweep_half(slb_solver *s, float cos_omega_t, float cos_omega_t_plus_dt);
 void slb_solver_swap(slb_solver *s);
+/* lattice 0 = main, 1 = half-step; local columns j_first..j_last clipped to the
+ * columns that sweep owns in this slab */
+void slb_solver_sweep_range(slb_solver *s, int lattice, int j_first, int j_last,
+                            float cos_omega_t, float cos_omega_t_plus_dt);
+/* t += dt, frame_time += dt (float accumulation), steps++ */
+void slb_solver_advance(slb_solver *s);
 
 /* cosines of one loop iteration at time t, formed as the reference forms them
  * (reference: src/boltzmann_solver.c:204-214): c[0..1] main sweep, c[2..3] half */
@@ -79,9 +85,10 @@ void slb_solver_step(slb_solver *s);
  * elapsed device time.  Single slab. */
 int slb_solver_run_timed(slb_solver *s, int steps, float *ms);
 
-/* halo columns of the arrays the NEXT sweep reads as stencil.
- * which: 0 = before the main sweep (the half-step lattice: a/b[current_hs]),
- *        1 = before the half sweep (the lattice just written: a/b[next]).
+/* halo columns of a lattice that a sweep reads as stencil.
+ * which: 0 = a/b[current_hs] (stencil of the main sweep),
+ *        1 = a/b[next]       (output of the main sweep, stencil of the half sweep),
+ *        2 = a/b[next_hs]    (output of the half sweep, next step's current_hs).
  * side:  0 = left neighbour (send my column 1, receive into column 0),
  *        1 = right neighbour (send my column W, receive into column W+1).
  * buf holds 2*(N+1) floats (device). */

@@ -149,6 +149,32 @@ void slb_solver_sweep_half(slb_solver *s, float c0, float c1)
                         s->a[s->next_hs], s->b[s->next_hs], c0, c1), __LINE__);
 }
 
+/* Part of a sweep: lattice 0 = main, 1 = half-step; local columns
+ * j_first..j_last, clipped to what that sweep owns.  Lets a driver update the
+ * slab's edge columns first, ship them, and update the interior meanwhile. */
+void slb_solver_sweep_range(slb_solver *s, int lattice, int j_first, int j_last, float c0, float c1)
+{
+  slb_slab part = lattice == 0 ? s->main_slab : s->half_slab;
+  if (j_first > part.j_first) part.j_first = j_first;
+  if (j_last < part.j_last)   part.j_last = j_last;
+  if (part.j_last < part.j_first) return;
+  if (lattice == 0)
+    check_sweep(slb_sweep(&part, s->a0, s->a[s->current], s->b[s->current],
+                          s->a[s->current_hs], s->b[s->current_hs],
+                          s->a[s->next], s->b[s->next], c0, c1), __LINE__);
+  else
+    check_sweep(slb_sweep(&part, s->a0, s->a[s->current_hs], s->b[s->current_hs],
+                          s->a[s->next], s->b[s->next],
+                          s->a[s->next_hs], s->b[s->next_hs], c0, c1), __LINE__);
+}
+
+void slb_solver_advance(slb_solver *s)
+{
+  s->t += host_dt;
+  s->frame_time += host_dt;
+  s->steps++;
+}
+
 void slb_solver_swap(slb_solver *s)
 {
   const int c = s->current, h = s->current_hs;
@@ -174,9 +200,7 @@ void slb_solver_step(slb_solver *s)
   slb_solver_sweep_main(s, c[0], c[1]);
   slb_solver_sweep_half(s, c[2], c[3]);
   slb_solver_swap(s);
-  s->t += host_dt;
-  s->frame_time += host_dt;
-  s->steps++;
+  slb_solver_advance(s);
 }
 
 int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
@@ -195,16 +219,21 @@ int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
   return 0;
 }
 
+static int halo_array(const slb_solver *s, int which)
+{
+  return which == 0 ? s->current_hs : (which == 1 ? s->next : s->next_hs);
+}
+
 int slb_solver_halo_pack(slb_solver *s, int which, int side, float *buf)
 {
-  const int idx = which == 0 ? s->current_hs : s->next;
+  const int idx = halo_array(s, which);
   const int col = side == 0 ? 1 : s->W;
   return slb_halo_pack(s->a[idx], s->b[idx], s->pitch, s->N + 1, col, buf);
 }
 
 int slb_solver_halo_unpack(slb_solver *s, int which, int side, const float *buf)
 {
-  const int idx = which == 0 ? s->current_hs : s->next;
+  const int idx = halo_array(s, which);
   const int col = side == 0 ? 0 : s->W + 1;
   return slb_halo_unpack(s->a[idx], s->b[idx], s->pitch, s->N + 1, col, buf);
 }

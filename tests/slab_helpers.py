@@ -1,0 +1,115 @@
+"""Helpers for the slab-partition tests: an engine with the HipEngine interface
+that computes with the CPU oracle (test infrastructure, never shipped), and the
+multi-process launcher."""
+import ctypes as C
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "super-lattice-boltzmann-2d_amd"
+
+
+def slab_columns(M, rank, world):
+    """(W, m_offset): owned columns and global index of local column 0
+    (same dealing-out rule as slb_solver_create)."""
+    base, rem = divmod(M, world)
+    W = base + (1 if rank < rem else 0)
+    first = 1 + rank * base + min(rank, rem)
+    return W, first - 1
+
+
+class OracleEngine:
+    def __init__(self, ob, p, rank, world):
+        import torch
+        self.torch = torch
+        self.ob, self.p, self.rank, self.world = ob, p, rank, world
+        self.N = p.N
+        self.W, self.m_offset = slab_columns(p.M, rank, world)
+        self.pitch = self.W + 3
+        last = rank == world - 1
+        self.j_last_main = self.W + (1 if last else 0)
+        self.j_last_half = self.W
+        rows = p.N + 1
+        a0_full = np.zeros((rows, p.M + 3), dtype=np.float32)
+        ob.lib().orc_init_a0(C.byref(p), a0_full)
+        self.a0 = np.ascontiguousarray(a0_full[:, self.m_offset:self.m_offset + self.pitch])
+        self.a = [np.zeros((rows, self.pitch), dtype=np.float32) for _ in range(4)]
+        self.b = [np.zeros((rows, self.pitch), dtype=np.float32) for _ in range(4)]
+        self.a[0][:] = self.a0
+        self.cur, self.nxt, self.cur_hs, self.nxt_hs = 0, 1, 2, 3
+        self.t = np.float32(0)
+
+    def new_buffer(self):
+        return self.torch.empty(2 * (self.N + 1), dtype=self.torch.float32)
+
+    def _sweep(self, j0, j1, ac, bc, a_s, b_s, ao, bo, c0, c1):
+        if j1 >= j0:
+            self.ob.sweep(self.p, self.pitch, self.m_offset, j0, j1, self.a0, ac, bc, a_s, b_s, ao, bo, c0, c1)
+
+    def tiptoe(self):
+        c1 = np.float32(np.cos(np.float64(np.float32(self.p.omega) * np.float32(self.p.dt))))
+        self._sweep(1, self.j_last_main, self.a[0], self.b[0], self.a[0], self.b[0],
+                    self.a[2], self.b[2], np.float32(1), c1)
+
+    def cosines(self):
+        f = np.float32
+        w, dt, t = f(self.p.omega), f(self.p.dt), self.t
+        t_hs = f(t + f(dt / f(2)))
+        cs = lambda x: f(np.cos(np.float64(x)))
+        return (cs(f(w * t)), cs(f(w * f(t + dt))), cs(f(w * t_hs)), cs(f(w * f(t_hs + dt))))
+
+    def sweep_range(self, lattice, j_first, j_last, c0, c1):
+        if lattice == 0:
+            j_last = min(j_last, self.j_last_main)
+            self._sweep(max(j_first, 1), j_last, self.a[self.cur], self.b[self.cur],
+                        self.a[self.cur_hs], self.b[self.cur_hs], self.a[self.nxt], self.b[self.nxt], c0, c1)
+        else:
+            j_last = min(j_last, self.j_last_half)
+            self._sweep(max(j_first, 1), j_last, self.a[self.cur_hs], self.b[self.cur_hs],
+                        self.a[self.nxt], self.b[self.nxt], self.a[self.nxt_hs], self.b[self.nxt_hs], c0, c1)
+
+    def _idx(self, which):
+        return (self.cur_hs, self.nxt, self.nxt_hs)[which]
+
+    def pack(self, which, side, buf):
+        i, col = self._idx(which), (1 if side == 0 else self.W)
+        buf.copy_(self.torch.from_numpy(np.concatenate([self.a[i][:, col], self.b[i][:, col]])))
+
+    def unpack(self, which, side, buf):
+        i, col = self._idx(which), (0 if side == 0 else self.W + 1)
+        v = buf.numpy()
+        self.a[i][:, col] = v[:self.N + 1]
+        self.b[i][:, col] = v[self.N + 1:]
+
+    def swap(self):
+        self.cur, self.nxt = self.nxt, self.cur
+        self.cur_hs, self.nxt_hs = self.nxt_hs, self.cur_hs
+
+    def advance(self):
+        self.t = np.float32(self.t + np.float32(self.p.dt))
+
+    def close(self):
+        pass
+
+    def owned(self, which, idx):
+        """owned columns (global 1..M, plus M+1.. on the last slab) of array idx"""
+        arr = (self.a if which == "a" else self.b)[idx]
+        hi = self.pitch if self.rank == self.world - 1 else self.W + 1
+        lo = 0 if self.rank == 0 else 1
+        return arr[:, lo:hi].copy()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def import_pkg():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    return importlib.import_module(PKG), importlib.import_module(PKG + ".dist")

@@ -1,0 +1,81 @@
+"""CPU-only checks of the boundary: the library loads, exports every symbol the
+header declares, and the program's command line behaves like the reference's."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "slb_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    funcs = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)) - {"defined"}
+    ext = re.findall(r"extern\s+(?:float|int)\s+([^;]+);", text)
+    globs = {g.strip() for decl in ext for g in decl.split(",")}
+    return funcs, globs
+
+
+def test_library_exports_every_declared_symbol(slb):
+    funcs, globs = _declared_symbols()
+    assert funcs == set(slb.ABI_FUNCTIONS)
+    assert globs == set(slb.ABI_GLOBALS)
+    L = slb.lib()
+    for name in funcs:
+        assert getattr(L, name) is not None
+    for name in globs:
+        C.c_int.in_dll(L, name)
+
+
+def test_derived_constants_follow_the_reference_formulas(slb):
+    d = slb.configure(N=32, M=4096, E_dc=1.0, E_omega=0.1, omega=1.0, mu=5.0, alpha=1.0, B=1.0,
+                      PhiYmin=-4.0, PhiYmax=4.0, dt=0.001)
+    import numpy as np
+    f = np.float32
+    assert d["host_dPhi"] == f(8.0) / f(4096)
+    assert d["host_nu"] == f(1) + f(0.001) / f(2)
+    assert d["host_nu2"] == f(d["host_nu"]) * f(d["host_nu"])
+    assert d["host_nu_tilde"] == f(1) - f(0.001) / f(2)
+    assert d["host_bdt"] == f(f(1.0) * f(0.001)) / f(f(4) * f(d["host_dPhi"]))
+    assert (d["MSIZE"], d["NSIZE"], d["host_TMSIZE"]) == (4099, 33, 4097)
+    assert d["PADDED_MSIZE"] == 4128 and d["PADDED_MSIZE"] * 4 % 128 == 0
+    # a row count that is already a multiple of 128 bytes is not padded further
+    d = slb.configure(N=4, M=3069, E_dc=1.0, E_omega=0.1, omega=1.0, mu=5.0, alpha=1.0, B=1.0,
+                      PhiYmin=-4.0, PhiYmax=4.0)
+    assert d["PADDED_MSIZE"] == 3072
+
+
+ARGS = ("display=4 E_dc=1 E_omega=0.1 omega=1 mu=5 alpha=1 n-harmonics=8 PhiYmin=-4 PhiYmax=4 "
+        "B=1 t-max=1").split()
+
+
+def _run(solver_bin, args, **kw):
+    return subprocess.run([solver_bin] + args, capture_output=True, text=True, timeout=60, **kw)
+
+
+def test_missing_required_parameter(solver_bin, tmp_path):
+    for drop, name in ((1, "E_dc"), (6, "n-harmonics"), (10, "t-max")):
+        args = [a for i, a in enumerate(ARGS) if i != drop] + ["o=stdout"]
+        r = _run(solver_bin, args, cwd=tmp_path)
+        assert r.returncode == 1
+        assert f'ERROR: Parameter "{name}" must be set.' in r.stderr
+    r = _run(solver_bin, ARGS[1:] + ["o=stdout"], cwd=tmp_path)
+    assert r.returncode == 1 and 'Parameter "display" must be set' in r.stderr
+
+
+def test_invalid_values(solver_bin, tmp_path):
+    r = _run(solver_bin, ["display=5"] + ARGS[1:] + ["o=stdout"], cwd=tmp_path)
+    assert r.returncode == 1 and "Invalid value of display= parameter" in r.stderr
+    r = _run(solver_bin, ARGS[:-1] + ["t-max=0", "o=stdout"], cwd=tmp_path)
+    assert r.returncode == 1 and "Invalid value of t-max= parameter" in r.stderr
+    r = _run(solver_bin, ARGS + ["read-from=file.txt", "o=stdout"], cwd=tmp_path)
+    assert r.returncode == 1 and "Invalid value of read-from=" in r.stderr
+    r = _run(solver_bin, ARGS + ["o=/nonexistent-dir/x.txt"], cwd=tmp_path)
+    assert r.returncode == 1 and 'Faled to open file "/nonexistent-dir/x.txt" for writing.' in r.stderr
+    # parsing stops at the first token without '=': everything after it is ignored
+    r = _run(solver_bin, ARGS[:3] + ["stop"] + ARGS[3:] + ["o=stdout"], cwd=tmp_path)
+    assert r.returncode == 1 and 'Parameter "omega" must be set' in r.stderr
+    # display modes that are out of scope are refused, not silently accepted
+    r = _run(solver_bin, ["display=7"] + ARGS[1:] + ["o=stdout"], cwd=tmp_path)
+    assert r.returncode == 1 and "display=7 is not available" in r.stderr

@@ -1,0 +1,66 @@
+"""The slab driver (super-lattice-boltzmann-2d_amd/dist.py) with world_size 2 and 3
+over gloo on CPU: partition + halo exchange + edge-first ordering must
+reproduce the single-domain oracle bit for bit.  The arithmetic here is the
+CPU oracle's (the test checks the driver's host logic, not the kernels)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import oracle_binding as ob          # noqa: E402
+import slab_helpers as sh            # noqa: E402
+
+PHYS = dict(N=6, M=101, B=0.6, omega=40.0, E_omega=0.3)
+STEPS = 7
+
+
+def _worker(rank, world, port, outdir):
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    slb, drv = sh.import_pkg()
+    p = ob.make_params(**PHYS)
+    eng = sh.OracleEngine(ob, p, rank, world)
+    run = drv.SlabRun(slb, rank, world, engine=eng)
+    run.tiptoe()
+    for _ in range(STEPS):
+        run.step()
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), t=eng.t,
+             idx=np.array([eng.cur, eng.nxt, eng.cur_hs, eng.nxt_hs]),
+             **{f"{w}{i}": eng.owned(w, i) for w in "ab" for i in range(4)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_driver_matches_single_domain(world, tmp_path):
+    mp.spawn(_worker, args=(world, sh.free_port(), str(tmp_path)), nprocs=world, join=True)
+    p = ob.make_params(**PHYS)
+    ref = ob.OracleState(p, threads=1)
+    ref.step(STEPS)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    assert all(np.float32(x["t"]) == np.float32(ref.st.t) for x in parts)
+    assert list(parts[0]["idx"]) == [ref.st.current, ref.st.next, ref.st.current_hs, ref.st.next_hs]
+    for w in "ab":
+        for i in range(4):
+            got = np.concatenate([x[f"{w}{i}"] for x in parts], axis=1)
+            exp = ref.array(w, i)
+            assert got.shape == exp.shape
+            assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (w, i)
+    ref.close()
+
+
+def test_slab_columns_cover_the_grid():
+    for M in (7, 100, 101, 4096):
+        for world in (1, 2, 3, 8):
+            if M < world:
+                continue
+            nxt = 1
+            for r in range(world):
+                W, off = sh.slab_columns(M, r, world)
+                assert off == nxt - 1 and W >= 1
+                nxt += W
+            assert nxt == M + 1

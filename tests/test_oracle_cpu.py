@@ -1,0 +1,96 @@
+"""CPU-only checks of the oracle: the recorded reference line, Bessel values,
+step counts, and slab/whole-domain consistency of the oracle's own sweep."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import scipy.special
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_oracle_reproduces_recorded_reference_line(oracle, tmp_path):
+    """config 1 (n-harmonics=32 g-grid=4096 t-max=10, 16 281 steps): the nine
+    computed columns of the display=4 line equal, digit for digit, the line the
+    compiled reference printed when it was surveyed."""
+    with open(os.path.join(GOLDEN, "config1_display4_reference.json")) as f:
+        gold = json.load(f)
+    out = tmp_path / "cfg1.txt"
+    r = oracle.run_cli(gold["args"].split() + [f"o={out}"], threads=8, timeout=900)
+    assert f"# t_max = {gold['t_max']}" in r.stdout
+    lines = out.read_text().splitlines()
+    assert len(lines) == 3 and lines[0].startswith("# display=4 E_dc=1.0000")
+    v = lines[2].split()
+    assert len(v) == 13
+    got = dict(zip(["v_dr/v_p", "A(omega)", "NORM", "v_y/v_p", "m/m_x", "<v_dr/v_p>", "<v_y/v_p>",
+                    "<m/m_x>", "Asin"], v[4:]))
+    assert got == gold["columns"]
+    assert re.fullmatch(r"# display=4 .* t-max=10\.0+ dt=0\.0010000000474974\d+ g-grid=4096", lines[0])
+
+
+def test_bessel_against_scipy(oracle, slb):
+    for x in (0.5, 5.0, 20.0):
+        for n in (0, 1, 2, 7, 32, 64, 128):
+            exp = scipy.special.iv(n, x)
+            for fn in (oracle.lib().orc_bessel_In, slb.lib().slb_bessel_In):
+                got = fn(n, x)
+                # scipy's own error grows to ~1e-14 for orders far above the argument
+                tol = 4e-15 if n <= 7 else 2e-13
+                assert abs(got - exp) <= tol * exp, (n, x, got, exp)
+    # far above the argument the value underflows double; 0 is the float image as well
+    assert oracle.lib().orc_bessel_In(512, 5.0) == 0.0
+    assert slb.lib().slb_bessel_In(512, 5.0) == 0.0
+    assert oracle.lib().orc_bessel_In(1, 5.0) == slb.lib().slb_bessel_In(1, 5.0)
+
+
+def _count_steps(oracle, dt, t_start, omega):
+    p = oracle.make_params(N=1, M=4, dt=dt, t_start=t_start, omega=omega)
+    st = oracle.OracleState(p, threads=1)
+    t, n = np.float32(0), 0
+    while t < np.float32(st.st.t_max):
+        t = np.float32(t + np.float32(dt))
+        n += 1
+    st.close()
+    return n
+
+
+def test_step_counts_from_float_time_accumulation(oracle):
+    assert _count_steps(oracle, 0.001, 10.0, 1.0) == 16281
+    assert _count_steps(oracle, 0.001, 0.05, 100.0) == 113
+    assert _count_steps(oracle, 0.001, 0.001, 100.0) == 64
+
+
+def test_oracle_sweep_is_slab_invariant(oracle):
+    """Updating a window of columns through a copied sub-array with a column
+    offset gives the same bits as updating the whole array."""
+    N, M = 9, 200
+    p = oracle.make_params(N=N, M=M, B=1.3, omega=5.0)
+    rng = np.random.default_rng(3)
+    rows, pitch = N + 1, M + 3
+    arrs = [(rng.standard_normal((rows, pitch)) * 0.1).astype(np.float32) for _ in range(7)]
+    a0, ac, bc, a_s, b_s, ao, bo = arrs
+    full_a, full_b = ao.copy(), bo.copy()
+    oracle.sweep(p, pitch, 0, 1, M + 1, a0, ac, bc, a_s, b_s, full_a, full_b, 0.3, 0.2)
+    lo, hi = 37, 121                       # window of owned columns, one ghost each side
+    sub = [np.ascontiguousarray(x[:, lo - 1:hi + 2]) for x in arrs]
+    oracle.sweep(p, hi - lo + 3, lo - 1, 1, hi - lo + 1, *sub[:5], sub[5], sub[6], 0.3, 0.2)
+    assert np.array_equal(sub[5][:, 1:-1].view(np.uint32), full_a[:, lo:hi + 1].view(np.uint32))
+    assert np.array_equal(sub[6][:, 1:-1].view(np.uint32), full_b[:, lo:hi + 1].view(np.uint32))
+    # untouched cells: row N, column 0 / M+2, row 0 of b
+    assert np.array_equal(full_a[N], ao[N]) and np.array_equal(full_b[0], bo[0])
+    assert np.array_equal(full_a[:, 0], ao[:, 0]) and np.array_equal(full_a[:, M + 2], ao[:, M + 2])
+
+
+def test_display77_trace_shape(oracle, tmp_path):
+    """Shrunken config 2: 113 steps give 11 records; NORM stays at 1 within 2e-4
+    and v_dr rises monotonically from the cold start."""
+    out = tmp_path / "t77.txt"
+    oracle.run_cli(("display=77 E_dc=1 E_omega=0.1 omega=100 mu=5 alpha=1 B=0.5 PhiYmin=-4 PhiYmax=4 "
+                    "n-harmonics=32 g-grid=8192 dt=0.001 t-max=0.05").split() + [f"o={out}"], threads=8)
+    rec = [l.split() for l in out.read_text().splitlines() if not l.startswith("#")]
+    assert len(rec) == 11 and all(len(r) == 15 for r in rec)
+    v_dr = [float(r[4]) for r in rec]
+    assert all(b > a for a, b in zip(v_dr, v_dr[1:])) and 0.03 < v_dr[0] < 0.08
+    assert all(abs(float(r[6]) - 1) < 2e-4 for r in rec)
