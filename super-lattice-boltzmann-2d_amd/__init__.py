@@ -107,6 +107,8 @@ def lib():
         L.slb_solver_halo_unpack.restype = i
         L.slb_solver_get_rows.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
         L.slb_solver_get_rows.restype = i
+        L.slb_solver_get_window.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
+        L.slb_solver_get_window.restype = i
         _lib = L
     return _lib
 
@@ -208,6 +210,16 @@ class Solver:
         rc = lib().slb_solver_get_rows(self._p, arr, row0, nrows, out.ctypes.data)
         if rc:
             raise RuntimeError(f"slb_solver_get_rows -> {rc}")
+        return out
+
+
+    def window(self, arr, col0, ncols):
+        """Columns [col0, col0+ncols) of every row of device array `arr`."""
+        import numpy as np
+        out = np.empty((self.s.N + 1, ncols), dtype=np.float32)
+        rc = lib().slb_solver_get_window(self._p, arr, col0, ncols, out.ctypes.data)
+        if rc:
+            raise RuntimeError(f"slb_solver_get_window -> {rc}")
         return out
 
 

@@ -99,6 +99,10 @@ int slb_solver_halo_unpack(slb_solver *s, int which, int side, const float *buf)
  * 5..8 = b[0..3]) into dst as nrows x pitch floats */
 int slb_solver_get_rows(slb_solver *s, int arr, int row0, int nrows, float *dst);
 
+/* copy columns [col0, col0+ncols) of all N+1 rows of device array `arr` into dst
+ * as (N+1) x ncols floats */
+int slb_solver_get_window(slb_solver *s, int arr, int col0, int ncols, float *dst);
+
 /* ---- display reductions on host rows (single slab) ----------------------
  * rows are passed with the DEVICE pitch; the sums index them the way the CPU
  * solver indexes its unpadded arrays, including its flat-index overrun. */

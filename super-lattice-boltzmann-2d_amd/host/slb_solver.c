@@ -247,6 +247,15 @@ int slb_solver_get_rows(slb_solver *s, int arr, int row0, int nrows, float *dst)
   return 0;
 }
 
+int slb_solver_get_window(slb_solver *s, int arr, int col0, int ncols, float *dst)
+{
+  if (arr < 0 || arr > 8 || col0 < 0 || ncols < 1 || col0 + ncols > s->pitch) return -1;
+  const float *src = arr == 0 ? s->a0 : (arr <= 4 ? s->a[arr - 1] : s->b[arr - 5]);
+  HIP_OK(hipMemcpy2D(dst, (size_t)ncols * sizeof(float), src + col0, (size_t)s->pitch * sizeof(float),
+                     (size_t)ncols * sizeof(float), (size_t)s->N + 1, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 /* ---- display reductions, evaluated on rows copied to the host ------------ */
 
 /* reference: src/boltzmann_c_solver.c:289-296 */

@@ -1,0 +1,70 @@
+"""Parity at BASELINE.json's full shapes.  The oracle cannot run whole lattices
+of this size in seconds, but it can run any WINDOW of columns (it takes a
+column offset), so each step of the GPU run is checked on windows at the left
+boundary, the centre and the right boundary, bit for bit; plus size-independent
+properties: the norm stays 1, untouched cells stay untouched."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ALL = list(range(9))         # 0 = a0, 1..4 = a[0..3], 5..8 = b[0..3]
+
+
+def _check_step_on_window(sol, slb, oracle, p, c0, c1):
+    """Take columns [c0, c1] of all nine arrays before a step, run the step on
+    the GPU, replay both sweeps of that step on the window with the oracle."""
+    s = sol.s
+    M, ncols = p.M, c1 - c0 + 1
+    before = [sol.window(k, c0, ncols) for k in ALL]
+    cur, nxt, chs, nhs = s.current, s.next, s.current_hs, s.next_hs
+    cos = slb.step_cosines(s.t)
+    sol.step()
+    a0 = before[0]
+    A = lambda i: before[1 + i]
+    B = lambda i: before[5 + i]
+    # main sweep: writable global columns 1..M+1, and the window's own edge columns lack a neighbour
+    g_lo, g_hi = max(c0 + 1, 1), min(c1 - 1, M + 1)
+    oracle.sweep(p, ncols, c0, g_lo - c0, g_hi - c0, a0, A(cur), B(cur), A(chs), B(chs), A(nxt), B(nxt),
+                 cos[0], cos[1])
+    # half sweep reads the main sweep's output one column to each side
+    h_lo, h_hi = max(g_lo + 1, 1) if c0 > 0 else 1, min(g_hi - 1, M)
+    oracle.sweep(p, ncols, c0, h_lo - c0, h_hi - c0, a0, A(chs), B(chs), A(nxt), B(nxt), A(nhs), B(nhs),
+                 cos[2], cos[3])
+    for idx, lo, hi in ((nxt, g_lo, g_hi), (nhs, h_lo, h_hi)):
+        for base, name in ((1, "a"), (5, "b")):
+            got = sol.window(base + idx, lo, hi - lo + 1)
+            exp = before[base + idx][:, lo - c0:hi - c0 + 1]
+            assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (name, idx, lo, hi)
+
+
+@pytest.mark.parametrize("N,M,steps", [
+    (128, 1 << 20, 3),       # config 3
+    (512, 1 << 20, 2),       # config 5: harmonic-heavy, I_n underflows to 0 for large n
+    (128, 1 << 23, 2),       # config 4 on a single GPU (39 GB)
+])
+def test_full_shape_windows_bit_exact(slb, oracle, N, M, steps):
+    p = oracle.make_params(N=N, M=M, B=4000.0 / M, omega=100.0)
+    slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    sol = slb.Solver()
+    try:
+        sol.tiptoe()
+        sol.step()
+        windows = [(0, 600), (M // 2 - 300, M // 2 + 300), (M // 2 + M // 8, M // 2 + M // 8 + 257),
+                   (M - 500, M + 2)]
+        for k in range(steps):
+            c0, c1 = windows[k % len(windows)]
+            _check_step_on_window(sol, slb, oracle, p, c0, c1)
+        for c0, c1 in windows[steps % len(windows):][:2]:
+            _check_step_on_window(sol, slb, oracle, p, c0, c1)
+        s = sol.s
+        # norm = 2 pi sqrt(alpha) sum_m a_0(m) dPhi stays 1 (double sum of the float terms)
+        row0 = sol.rows(1 + s.current, 0, 1)[0]
+        norm = 2 * np.pi * np.sqrt(p.alpha) * np.sum(row0[1:M + 1].astype(np.float64) * p.dPhi)
+        assert abs(norm - 1) < 2e-4
+        # cells no sweep may write: row N of a zero-initialised buffer, row 0 of b
+        assert not sol.rows(1 + 1, N, 1).any()
+        assert not sol.rows(5 + s.current, 0, 1).any()
+    finally:
+        sol.close()
