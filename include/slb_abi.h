@@ -98,6 +98,29 @@ int slb_sweep(const slb_slab *slab,
               float *a_out, float *b_out,
               float cos_omega_t, float cos_omega_t_plus_dt);
 
+/* Geometry of a fused step (both sweeps in one launch) on one slab. */
+typedef struct slb_step_geom {
+  int pitch;                /* floats per row, a multiple of 4                        */
+  int m_offset;             /* global column index of local column 0                  */
+  int j1_first, j1_last;    /* local columns the main-lattice sweep writes            */
+  int j2_first, j2_last;    /* local columns the half-step-lattice sweep writes       */
+} slb_step_geom;
+
+/* One whole loop iteration in one launch: step_on_grid followed by
+ * step_on_half_grid (reference: src/boltzmann_solver.c:204-217), with the main
+ * sweep's output handed to the half-step sweep inside the kernel instead of
+ * through memory.  Results are bit-identical to the two separate calls.
+ * cosines[0..1] belong to the main sweep, [2..3] to the half-step sweep.
+ * Every column the half-step sweep reads at m+-1 must either be written by the
+ * main sweep of this call (j1 range) or be a column no sweep ever writes
+ * (then its present contents are used, as in the two-call form).  A
+ * single-GPU step is {PADDED_MSIZE, 0, 1, M+1, 1, M}.  Returns like slb_sweep. */
+int slb_step_fused(const slb_step_geom *geom,
+                   const float *a0, const float *a_current, const float *b_current,
+                   const float *a_current_hs, const float *b_current_hs,
+                   float *a_next, float *b_next, float *a_next_hs, float *b_next_hs,
+                   const float cosines[4]);
+
 /* Gather local column `col` of rows 0..nrows-1 of arrays a and b into
  * buf[0..nrows-1] and buf[nrows..2*nrows-1]; and the inverse scatter. */
 int slb_halo_pack  (const float *a, const float *b, int pitch, int nrows, int col, float *buf);
@@ -130,7 +153,9 @@ void *slb_get_stream(void);
 /* Sweep kernel selection: variant 0 = auto, 1 = one column per lane,
  * 2 = four columns per lane with neighbour columns re-read through L1,
  * 3 = four columns per lane with neighbour columns taken from the adjacent
- * lanes (cross-lane), 4 = like 3 with the stencil rows staged through LDS.
+ * lanes (cross-lane), 4 = software-pipelined form of 2, 5 = 4 with nontemporal
+ * accesses for data touched once.  For slb_step_fused: 6 = plain accesses,
+ * anything else = nontemporal.
  * n_chunk = rows per workgroup in n (0 = auto), block = threads (0 = auto). */
 void slb_set_tuning(int variant, int n_chunk, int block);
 

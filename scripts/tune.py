@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--variants", default="2,3")
     ap.add_argument("--chunks", default="0,8,16,32,64,128")
     ap.add_argument("--blocks", default="256,128,64")
+    ap.add_argument("--fused", action="store_true", help="time the one-launch step (variants 6, 7)")
     args = ap.parse_args()
     import torch
     slb = importlib.import_module("super-lattice-boltzmann-2d_amd")
@@ -28,15 +29,19 @@ def main():
     L = slb.lib()
     sol = slb.Solver()
     sol.tiptoe()
+    sol.set_fused(args.fused)
+    per_launch = 1 if args.fused else 2
+    bytes_per_point = 36.0 if args.fused else 28.0
     for v in [int(x) for x in args.variants.split(",")]:
         for nc in [int(x) for x in args.chunks.split(",")]:
             for b in [int(x) for x in args.blocks.split(",")]:
                 L.slb_set_tuning(v, nc, b)
                 sol.run_timed(3)
-                ms = min(sol.run_timed(args.steps) for _ in range(3)) / (2 * args.steps)
-                gbs = 28.0 * N * (M + 0.5) / (ms * 1e-3) / 1e9
-                print(f"variant={v} n_chunk={nc:4d} block={b:4d}  {ms:8.4f} ms/sweep  {gbs:8.1f} GB/s  "
-                      f"{gbs / 80.0:5.1f}% of 8 TB/s", flush=True)
+                ms = min(sol.run_timed(args.steps) for _ in range(3)) / (per_launch * args.steps)
+                gbs = bytes_per_point * N * (M + 0.5) / (ms * 1e-3) / 1e9
+                ups = N * M / (ms * per_launch * 1e-3)
+                print(f"variant={v} n_chunk={nc:4d} block={b:4d}  {ms:8.4f} ms/launch  {gbs:8.1f} GB/s  "
+                      f"{gbs / 80.0:5.1f}% of 8 TB/s  {ups:.3e} updates/s", flush=True)
     sol.close()
 
 

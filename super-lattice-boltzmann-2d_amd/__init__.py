@@ -23,7 +23,7 @@ _INT_GLOBALS = ("host_M", "host_N", "MSIZE", "MP1", "NSIZE", "host_TMSIZE", "PAD
 
 # every symbol include/slb_abi.h declares
 ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "HandleError",
-                 "slb_sweep", "slb_halo_pack", "slb_halo_unpack", "slb_av_partial",
+                 "slb_sweep", "slb_step_fused", "slb_halo_pack", "slb_halo_unpack", "slb_av_partial",
                  "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream",
                  "slb_set_tuning", "slb_version")
 ABI_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha",
@@ -38,6 +38,11 @@ class Slab(C.Structure):
     _fields_ = [("pitch", C.c_int), ("m_offset", C.c_int), ("j_first", C.c_int), ("j_last", C.c_int)]
 
 
+class StepGeom(C.Structure):
+    _fields_ = [("pitch", C.c_int), ("m_offset", C.c_int), ("j1_first", C.c_int), ("j1_last", C.c_int),
+                ("j2_first", C.c_int), ("j2_last", C.c_int)]
+
+
 class SolverStruct(C.Structure):
     """Mirror of ``slb_solver`` in host/slb_host.h."""
     _fields_ = [("N", C.c_int), ("M", C.c_int), ("rank", C.c_int), ("nranks", C.c_int),
@@ -46,7 +51,7 @@ class SolverStruct(C.Structure):
                 ("a0", C.c_void_p), ("a", C.c_void_p * 4), ("b", C.c_void_p * 4),
                 ("av_data", C.c_void_p), ("sums", C.c_void_p), ("halo_buf", C.c_void_p),
                 ("current", C.c_int), ("next", C.c_int), ("current_hs", C.c_int), ("next_hs", C.c_int),
-                ("t", C.c_float), ("frame_time", C.c_float), ("steps", C.c_long)]
+                ("t", C.c_float), ("frame_time", C.c_float), ("steps", C.c_long), ("fused", C.c_int)]
 
 
 _lib = None
@@ -70,6 +75,8 @@ def lib():
         L.av.argtypes, L.av.restype = [i, fp, fp, fp, f], None
         L.slb_sweep.argtypes = [C.POINTER(Slab)] + [fp] * 7 + [f, f]
         L.slb_sweep.restype = i
+        L.slb_step_fused.argtypes = [C.POINTER(StepGeom)] + [fp] * 9 + [C.POINTER(C.c_float * 4)]
+        L.slb_step_fused.restype = i
         L.slb_halo_pack.argtypes = [fp, fp, i, i, i, fp]
         L.slb_halo_pack.restype = i
         L.slb_halo_unpack.argtypes = [fp, fp, i, i, i, fp]
@@ -99,6 +106,7 @@ def lib():
         L.slb_solver_advance.argtypes, L.slb_solver_advance.restype = [C.POINTER(SolverStruct)], None
         L.slb_step_cosines.argtypes, L.slb_step_cosines.restype = [f, C.POINTER(C.c_float * 4)], None
         L.slb_solver_step.argtypes, L.slb_solver_step.restype = [C.POINTER(SolverStruct)], None
+        L.slb_solver_step_fused.argtypes, L.slb_solver_step_fused.restype = [C.POINTER(SolverStruct)], None
         L.slb_solver_run_timed.argtypes = [C.POINTER(SolverStruct), i, C.POINTER(C.c_float)]
         L.slb_solver_run_timed.restype = i
         L.slb_solver_halo_pack.argtypes = [C.POINTER(SolverStruct), i, i, fp]
@@ -167,6 +175,12 @@ class Solver:
 
     def step(self):
         lib().slb_solver_step(self._p)
+
+    def step_fused(self):
+        lib().slb_solver_step_fused(self._p)
+
+    def set_fused(self, on):
+        self._p.contents.fused = 1 if on else 0
 
     def sweep_main(self, c0, c1):
         lib().slb_solver_sweep_main(self._p, c0, c1)

@@ -51,8 +51,9 @@ struct SweepArgs {
 // ---------------------------------------------------------------------------
 // Ap/Am (Bp/Bm): stencil arrays at row n+1, columns m+1 / m-1.
 // dA_lo/dB_lo:   A[n-1][m+1]-A[n-1][m-1] and the same for B (any value if n==0).
+template <class Params>
 __device__ __forceinline__ void point_update(
-    const SweepArgs &p, int n, float fn, float mu_part, float mu1_part,
+    const Params &p, int n, float fn, float mu_part, float mu1_part,
     float a0v, float ac, float bc, float Ap, float Am, float Bp, float Bm,
     float dA_lo, float dB_lo, float &a_new, float &b_new)
 {
@@ -221,6 +222,347 @@ sweep_kernel(const SweepArgs p)
 }
 
 // ---------------------------------------------------------------------------
+// software-pipelined sweep: same arithmetic, four columns per lane; the loads of
+// row n+1 are issued before row n is computed, so a wave keeps two rows of
+// loads in flight.  Row bases are wave-uniform (SGPR base + 32-bit lane offset).
+// NT: centre arrays / outputs, which are touched once per sweep, bypass the
+// cache hierarchy's retention (nontemporal).
+// ---------------------------------------------------------------------------
+struct RowRegs {
+  float ea[6], eb[6], a0v[4], ac[4], bc[4];
+};
+
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float *base, unsigned off)
+{
+  const float4 *q = reinterpret_cast<const float4 *>(base + off);
+  if constexpr (NT) {
+    float4 v;
+    v.x = __builtin_nontemporal_load(&q->x); v.y = __builtin_nontemporal_load(&q->y);
+    v.z = __builtin_nontemporal_load(&q->z); v.w = __builtin_nontemporal_load(&q->w);
+    return v;
+  } else {
+    return *q;
+  }
+}
+
+template <bool NT>
+__device__ __forceinline__ void st4(float *base, unsigned off, const float (&r)[4])
+{
+  float4 *q = reinterpret_cast<float4 *>(base + off);
+  if constexpr (NT) {
+    __builtin_nontemporal_store(r[0], &q->x); __builtin_nontemporal_store(r[1], &q->y);
+    __builtin_nontemporal_store(r[2], &q->z); __builtin_nontemporal_store(r[3], &q->w);
+  } else {
+    *q = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(256)
+sweep_pipe_kernel(const SweepArgs p)
+{
+  constexpr int V = 4;
+  const int jj = p.jj0 + (blockIdx.x * blockDim.x + threadIdx.x) * V;
+  if (jj > p.j_last) return;
+  const unsigned j  = (unsigned)jj;                       // jj <= j_last <= pitch-2, pitch % 4 == 0
+  const unsigned jl = jj > 0 ? j - 1 : 0;
+  const unsigned jr = jj + V < p.pitch ? j + V : (unsigned)p.pitch - 1;
+
+  const int n0 = blockIdx.y * p.n_chunk;
+  const int n1 = n0 + p.n_chunk < p.N ? n0 + p.n_chunk : p.N;
+
+  float mu_part[V], mu1_part[V];
+  bool  wr[V];
+  bool  wr_all = true;
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    const int   m   = p.m_offset + jj + k;
+    const float phi = p.PhiYmin + p.dPhi * (float)(m - 1);
+    mu_part[k]  = ((p.E_dc + p.E_omega * p.cos_t)  + p.B * phi) * p.dt / 2.0f;
+    mu1_part[k] = ((p.E_dc + p.E_omega * p.cos_t1) + p.B * phi) * p.dt / 2.0f;
+    wr[k]  = (jj + k >= p.j_first) && (jj + k <= p.j_last);
+    wr_all = wr_all && wr[k];
+  }
+
+  const size_t P = (size_t)p.pitch;
+
+  auto stencil_diffs = [&](int r, float (&dAq)[V], float (&dBq)[V]) {
+    const float *as = p.a_s + (size_t)r * P, *bs = p.b_s + (size_t)r * P;
+    const float4 va = ld4<false>(as, j), vb = ld4<false>(bs, j);
+    const float al = as[jl], ar = as[jr], bl = bs[jl], br = bs[jr];
+    dAq[0] = va.y - al;   dAq[1] = va.z - va.x; dAq[2] = va.w - va.y; dAq[3] = ar - va.z;
+    dBq[0] = vb.y - bl;   dBq[1] = vb.z - vb.x; dBq[2] = vb.w - vb.y; dBq[3] = br - vb.z;
+  };
+
+  float dA[2][V], dB[2][V];
+  if (n0 >= 1) {
+    stencil_diffs(n0 - 1, dA[0], dB[0]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < V; k++) { dA[0][k] = 0.0f; dB[0][k] = 0.0f; }
+  }
+  stencil_diffs(n0, dA[1], dB[1]);
+
+  auto issue = [&](int n, RowRegs &r) {
+    const size_t row = (size_t)n * P;                      // wave-uniform
+    const float *as = p.a_s + row + P, *bs = p.b_s + row + P;
+    const float4 va = ld4<false>(as, j), vb = ld4<false>(bs, j);
+    r.ea[0] = as[jl]; r.ea[1] = va.x; r.ea[2] = va.y; r.ea[3] = va.z; r.ea[4] = va.w; r.ea[5] = as[jr];
+    r.eb[0] = bs[jl]; r.eb[1] = vb.x; r.eb[2] = vb.y; r.eb[3] = vb.z; r.eb[4] = vb.w; r.eb[5] = bs[jr];
+    const float4 v0 = ld4<NT>(p.a0 + row, j), v1 = ld4<NT>(p.a_c + row, j), v2 = ld4<NT>(p.b_c + row, j);
+    r.a0v[0] = v0.x; r.a0v[1] = v0.y; r.a0v[2] = v0.z; r.a0v[3] = v0.w;
+    r.ac[0] = v1.x;  r.ac[1] = v1.y;  r.ac[2] = v1.z;  r.ac[3] = v1.w;
+    r.bc[0] = v2.x;  r.bc[1] = v2.y;  r.bc[2] = v2.z;  r.bc[3] = v2.w;
+  };
+
+  auto finish = [&](int n, const RowRegs &r, float (&dAq)[V], float (&dBq)[V]) {
+    float an[V], bn[V];
+    const float fn = (float)n;
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      point_update(p, n, fn, mu_part[k], mu1_part[k], r.a0v[k], r.ac[k], r.bc[k],
+                   r.ea[k + 2], r.ea[k], r.eb[k + 2], r.eb[k], dAq[k], dBq[k], an[k], bn[k]);
+      dAq[k] = r.ea[k + 2] - r.ea[k];
+      dBq[k] = r.eb[k + 2] - r.eb[k];
+    }
+    const size_t row = (size_t)n * P;
+    float *ao = p.a_out + row, *bo = p.b_out + row;
+    if (wr_all) {
+      st4<NT>(ao, j, an);
+      if (n > 0) st4<NT>(bo, j, bn);
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; k++) {
+        if (wr[k]) {
+          ao[j + k] = an[k];
+          if (n > 0) bo[j + k] = bn[k];
+        }
+      }
+    }
+  };
+
+  RowRegs r0, r1;
+  issue(n0, r0);
+  int n = n0;
+  while (n + 1 < n1) {
+    issue(n + 1, r1);
+    finish(n, r0, dA[0], dB[0]);
+    if (n + 2 < n1) issue(n + 2, r0);
+    finish(n + 1, r1, dA[1], dB[1]);
+    n += 2;
+  }
+  if (n < n1) finish(n, r0, dA[0], dB[0]);
+}
+
+// ---------------------------------------------------------------------------
+// fused step: both sweeps of one loop iteration in one pass over the lattice.
+//
+// The half-step sweep at (n, m) reads the main sweep's output at (n+-1, m+-1)
+// (reference: src/boltzmann_c_solver.c:399-402 read a_next/b_next written at
+// :375-377).  A lane owns four columns and walks n upward; when it has the main
+// sweep's row r it immediately forms the half-step row r-1, taking the m+-1
+// values of row r from the adjacent lanes (DPP wave shifts) instead of from
+// memory.  Lanes 0 and 63 of every wave are halo lanes: they recompute the main
+// sweep for the columns next to the wave's 62 interior lanes and store nothing,
+// so a wave needs no other wave and no barrier.  Traffic per lattice-point
+// update: 5 reads (a0, a, b, a_hs, b_hs) + 4 writes = 36 B instead of 56 B.
+// Every value is produced by the same point_update() in the same order as in
+// the two-launch form, so results are bit-identical to it.
+// ---------------------------------------------------------------------------
+struct FusedArgs {
+  const float *a0, *a_c, *b_c, *a_h, *b_h;   // a0; main lattice (t); half-step lattice (t+dt/2)
+  float *a_n, *b_n, *a_hn, *b_hn;            // main lattice (t+dt); half-step lattice (t+3dt/2)
+  float E_dc, E_omega, B, dt, dPhi, PhiYmin, nu, nu2, nu_tilde, bdt, c0, c1, c2, c3;
+  int N, pitch, m_offset, n_chunk, jj0;
+  int j1_first, j1_last;                     // columns the main sweep writes
+  int j2_first, j2_last;                     // columns the half-step sweep writes
+};
+
+// value of lane-1 / lane+1 (lane 0 / lane 63 get 0; they never use it)
+__device__ __forceinline__ float from_left_lane(float v)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_right_lane(float v)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// own[0..3] -> e[0..5] = columns j-1 .. j+4 using the adjacent lanes
+__device__ __forceinline__ void widen(const float (&own)[4], float (&e)[6])
+{
+  e[0] = from_left_lane(own[3]);
+  e[1] = own[0]; e[2] = own[1]; e[3] = own[2]; e[4] = own[3];
+  e[5] = from_right_lane(own[0]);
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(256)
+fused_step_kernel(const FusedArgs p)
+{
+  constexpr int V = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int jj   = p.jj0 + (wave * 62 + lane - 1) * V;          // first own column (may be < 0)
+  const int j_hi = p.j1_last > p.j2_last ? p.j1_last : p.j2_last;
+  if (p.jj0 + wave * 62 * V > j_hi) return;                     // whole wave past the end
+  const bool interior = lane >= 1 && lane <= 62;
+  // columns used for addressing stay inside the row; lanes that were clamped never store
+  const int jcl = jj < 0 ? 0 : (jj > p.pitch - V ? p.pitch - V : jj);
+  const unsigned j = (unsigned)jcl;
+
+  const int n0 = blockIdx.y * p.n_chunk;
+  const int n1 = n0 + p.n_chunk < p.N ? n0 + p.n_chunk : p.N;
+  const int r_lo  = n0 > 0 ? n0 - 1 : 0;        // first main-sweep row this workgroup forms
+  const int r_end = n1;                         // last row needed: n1 (row N comes from memory)
+
+  float mu1a[V], mu1b[V], mu2a[V], mu2b[V];
+  bool  w1[V], w2[V], ok1[V];
+  bool  w1_all = true, w2_all = true, need_old = false;
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    const int   c   = jj + k;
+    const float phi = p.PhiYmin + p.dPhi * (float)(p.m_offset + c - 1);
+    mu1a[k] = ((p.E_dc + p.E_omega * p.c0) + p.B * phi) * p.dt / 2.0f;
+    mu1b[k] = ((p.E_dc + p.E_omega * p.c1) + p.B * phi) * p.dt / 2.0f;
+    mu2a[k] = ((p.E_dc + p.E_omega * p.c2) + p.B * phi) * p.dt / 2.0f;
+    mu2b[k] = ((p.E_dc + p.E_omega * p.c3) + p.B * phi) * p.dt / 2.0f;
+    ok1[k] = c >= p.j1_first && c <= p.j1_last;               // the main sweep produces this column
+    w1[k]  = interior && ok1[k];
+    w2[k]  = interior && c >= p.j2_first && c <= p.j2_last;
+    w1_all = w1_all && w1[k];
+    w2_all = w2_all && w2[k];
+    // a column the half-step sweep reads but the main sweep does not write keeps its old value
+    if (!ok1[k] && c >= p.j2_first - 1 && c <= p.j2_last + 1 && c >= 0 && c < p.pitch) need_old = true;
+  }
+  if (jj != jcl) need_old = false;
+
+  const size_t P = (size_t)p.pitch;
+
+  // sliding state (rows relative to the main-sweep row r of the current iteration)
+  float dhA_p[V], dhB_p[V];      // half-step lattice, row r-1: X[m+1]-X[m-1]
+  float dhA_c[V], dhB_c[V];      //                    row r
+  float hA_p[V], hB_p[V];        // half-step lattice, row r-1, own columns (centre of half sweep)
+  float hA_c[V], hB_c[V];        //                    row r
+  float a0_p[V];                 // a0 row r-1
+  float d1A_pp[V], d1B_pp[V];    // main-sweep output, row r-2: X[m+1]-X[m-1]
+  float d1A_p[V], d1B_p[V];      //                    row r-1
+
+  auto load_h = [&](int r, float (&ownA)[V], float (&ownB)[V], float (&dA)[V], float (&dB)[V]) {
+    const float4 va = ld4<NT>(p.a_h + (size_t)r * P, j), vb = ld4<NT>(p.b_h + (size_t)r * P, j);
+    ownA[0] = va.x; ownA[1] = va.y; ownA[2] = va.z; ownA[3] = va.w;
+    ownB[0] = vb.x; ownB[1] = vb.y; ownB[2] = vb.z; ownB[3] = vb.w;
+    float ea[6], eb[6];
+    widen(ownA, ea); widen(ownB, eb);
+#pragma unroll
+    for (int k = 0; k < V; k++) { dA[k] = ea[k + 2] - ea[k]; dB[k] = eb[k + 2] - eb[k]; }
+  };
+
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    dhA_p[k] = dhB_p[k] = 0.0f; hA_p[k] = hB_p[k] = 0.0f; a0_p[k] = 0.0f;
+    d1A_pp[k] = d1B_pp[k] = d1A_p[k] = d1B_p[k] = 0.0f;
+  }
+  if (r_lo >= 1) load_h(r_lo - 1, hA_p, hB_p, dhA_p, dhB_p);
+  load_h(r_lo, hA_c, hB_c, dhA_c, dhB_c);
+
+  for (int r = r_lo; r <= r_end; r++) {
+    float o1A[V], o1B[V];          // main-sweep output row r, own columns
+    float a0_r[V];
+    float hA_n[V], hB_n[V], dhA_n[V], dhB_n[V];
+    const size_t row = (size_t)r * P;
+    if (r < p.N) {
+      // ---- main sweep, row r ----
+      const float4 v0 = ld4<NT>(p.a0 + row, j), v1 = ld4<NT>(p.a_c + row, j), v2 = ld4<NT>(p.b_c + row, j);
+      const float ac[V] = {v1.x, v1.y, v1.z, v1.w}, bc[V] = {v2.x, v2.y, v2.z, v2.w};
+      a0_r[0] = v0.x; a0_r[1] = v0.y; a0_r[2] = v0.z; a0_r[3] = v0.w;
+      const float4 va = ld4<NT>(p.a_h + row + P, j), vb = ld4<NT>(p.b_h + row + P, j);
+      hA_n[0] = va.x; hA_n[1] = va.y; hA_n[2] = va.z; hA_n[3] = va.w;
+      hB_n[0] = vb.x; hB_n[1] = vb.y; hB_n[2] = vb.z; hB_n[3] = vb.w;
+      float ea[6], eb[6];
+      widen(hA_n, ea); widen(hB_n, eb);
+      const float fr = (float)r;
+#pragma unroll
+      for (int k = 0; k < V; k++) {
+        point_update(p, r, fr, mu1a[k], mu1b[k], a0_r[k], ac[k], bc[k],
+                     ea[k + 2], ea[k], eb[k + 2], eb[k], dhA_p[k], dhB_p[k], o1A[k], o1B[k]);
+        dhA_n[k] = ea[k + 2] - ea[k];
+        dhB_n[k] = eb[k + 2] - eb[k];
+      }
+      if (r >= n0 && r < n1) {
+        if (w1_all) {
+          st4<NT>(p.a_n + row, j, o1A);
+          if (r > 0) st4<NT>(p.b_n + row, j, o1B);
+        } else {
+#pragma unroll
+          for (int k = 0; k < V; k++) {
+            if (w1[k]) {
+              p.a_n[row + j + k] = o1A[k];
+              if (r > 0) p.b_n[row + j + k] = o1B[k];
+            }
+          }
+        }
+      }
+      if (need_old) {
+        // columns the main sweep does not write keep their present contents.  (Row 0 of b
+        // is not written either, but no update ever reads it: the n-1 term is dropped for n<2.)
+        const float4 oa = *reinterpret_cast<const float4 *>(p.a_n + row + j);
+        const float4 ob = *reinterpret_cast<const float4 *>(p.b_n + row + j);
+        const float olda[V] = {oa.x, oa.y, oa.z, oa.w}, oldb[V] = {ob.x, ob.y, ob.z, ob.w};
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+          if (!ok1[k]) { o1A[k] = olda[k]; o1B[k] = oldb[k]; }
+        }
+      }
+    } else {
+      // row N is never written by the main sweep: its present contents are the stencil
+      const float4 oa = *reinterpret_cast<const float4 *>(p.a_n + row + j);
+      const float4 ob = *reinterpret_cast<const float4 *>(p.b_n + row + j);
+      o1A[0] = oa.x; o1A[1] = oa.y; o1A[2] = oa.z; o1A[3] = oa.w;
+      o1B[0] = ob.x; o1B[1] = ob.y; o1B[2] = ob.z; o1B[3] = ob.w;
+#pragma unroll
+      for (int k = 0; k < V; k++) { a0_r[k] = 0.0f; hA_n[k] = hB_n[k] = dhA_n[k] = dhB_n[k] = 0.0f; }
+    }
+
+    // ---- half-step sweep, row r-1, from main rows r (here) and r-2 (differences kept) ----
+    float e1a[6], e1b[6];
+    widen(o1A, e1a); widen(o1B, e1b);
+    const int n = r - 1;
+    if (n >= n0) {
+      float o2A[V], o2B[V];
+      const float fn = (float)n;
+      const size_t rown = (size_t)n * P;
+#pragma unroll
+      for (int k = 0; k < V; k++)
+        point_update(p, n, fn, mu2a[k], mu2b[k], a0_p[k], hA_p[k], hB_p[k],
+                     e1a[k + 2], e1a[k], e1b[k + 2], e1b[k], d1A_pp[k], d1B_pp[k], o2A[k], o2B[k]);
+      if (w2_all) {
+        st4<NT>(p.a_hn + rown, j, o2A);
+        if (n > 0) st4<NT>(p.b_hn + rown, j, o2B);
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+          if (w2[k]) {
+            p.a_hn[rown + j + k] = o2A[k];
+            if (n > 0) p.b_hn[rown + j + k] = o2B[k];
+          }
+        }
+      }
+    }
+    // ---- slide the window one row up ----
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      d1A_pp[k] = d1A_p[k];               d1B_pp[k] = d1B_p[k];
+      d1A_p[k]  = e1a[k + 2] - e1a[k];    d1B_p[k]  = e1b[k + 2] - e1b[k];
+      dhA_p[k] = dhA_c[k]; dhB_p[k] = dhB_c[k]; dhA_c[k] = dhA_n[k]; dhB_c[k] = dhB_n[k];
+      hA_p[k] = hA_c[k];   hB_p[k] = hB_c[k];   hA_c[k] = hA_n[k];   hB_c[k] = hB_n[k];
+      a0_p[k] = a0_r[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // halo movers: one column of rows 0..nrows-1 of two arrays <-> contiguous buffer
 // ---------------------------------------------------------------------------
 __global__ void halo_pack_kernel(const float *a, const float *b, int pitch, int nrows, int col, float *buf)
@@ -382,6 +724,31 @@ int launch_sweep(SweepArgs &args, int block)
   return (int)hipGetLastError();
 }
 
+template <bool NT>
+int launch_pipe(SweepArgs &args, int block)
+{
+  args.jj0 = args.j_first / 4 * 4;
+  const int cols  = args.j_last + 1 - args.jj0;
+  const int lanes = (cols + 3) / 4;
+  dim3 grid((lanes + block - 1) / block, (args.N + args.n_chunk - 1) / args.n_chunk);
+  hipLaunchKernelGGL((sweep_pipe_kernel<NT>), grid, dim3(block), 0, g_stream, args);
+  return (int)hipGetLastError();
+}
+
+template <bool NT>
+int launch_fused(FusedArgs &args, int block)
+{
+  const int lo = args.j1_first < args.j2_first ? args.j1_first : args.j2_first;
+  const int hi = args.j1_last > args.j2_last ? args.j1_last : args.j2_last;
+  args.jj0 = lo / 4 * 4;
+  const int per_wave = 62 * 4;                          // columns a wave's interior lanes cover
+  const int waves = (hi + 1 - args.jj0 + per_wave - 1) / per_wave;
+  const int wpb = block / 64;
+  dim3 grid((waves + wpb - 1) / wpb, (args.N + args.n_chunk - 1) / args.n_chunk);
+  hipLaunchKernelGGL((fused_step_kernel<NT>), grid, dim3(block), 0, g_stream, args);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -469,10 +836,57 @@ int slb_sweep(const slb_slab *slab,
     case 1:  return launch_sweep<1, 0>(s, block);
     case 2:  return launch_sweep<4, 0>(s, block);
     case 3:  return launch_sweep<4, 1>(s, block);
+    case 4:  return launch_pipe<false>(s, block);
+    case 5:  return launch_pipe<true>(s, block);
     default:
       fprintf(stderr, "slb_sweep: unknown variant %d\n", variant);
       return -1;
   }
+}
+
+int slb_step_fused(const slb_step_geom *g,
+                   const float *a0, const float *a_current, const float *b_current,
+                   const float *a_current_hs, const float *b_current_hs,
+                   float *a_next, float *b_next, float *a_next_hs, float *b_next_hs,
+                   const float cosines[4])
+{
+  if (!g_phys.loaded) { fprintf(stderr, "slb_step_fused: load_data() has not been called\n"); return -1; }
+  if (!g || g->pitch < 4 || g->pitch % 4 != 0 || g->j1_first < 1 || g->j2_first < 1 ||
+      g->j1_last > g->pitch - 2 || g->j2_last > g->pitch - 2 || g_phys.N < 1) {
+    fprintf(stderr, "slb_step_fused: bad geometry\n");
+    return -1;
+  }
+  // the half-step sweep may only read main-sweep columns that are produced here or are
+  // genuinely never written (global boundary columns hold their old value)
+  const void *ptrs[9] = {a0, a_current, b_current, a_current_hs, b_current_hs, a_next, b_next, a_next_hs, b_next_hs};
+  for (int i = 0; i < 9; i++)
+    if (!aligned16(ptrs[i])) { fprintf(stderr, "slb_step_fused: arrays must be 16-byte aligned\n"); return -1; }
+  if (g->j1_last < g->j1_first && g->j2_last < g->j2_first) return 0;
+
+  FusedArgs s;
+  s.a0 = a0; s.a_c = a_current; s.b_c = b_current; s.a_h = a_current_hs; s.b_h = b_current_hs;
+  s.a_n = a_next; s.b_n = b_next; s.a_hn = a_next_hs; s.b_hn = b_next_hs;
+  s.E_dc = g_phys.E_dc; s.E_omega = g_phys.E_omega; s.B = g_phys.B; s.dt = g_phys.dt;
+  s.dPhi = g_phys.dPhi; s.PhiYmin = g_phys.PhiYmin; s.nu = g_phys.nu; s.nu2 = g_phys.nu2;
+  s.nu_tilde = g_phys.nu_tilde; s.bdt = g_phys.bdt;
+  s.c0 = cosines[0]; s.c1 = cosines[1]; s.c2 = cosines[2]; s.c3 = cosines[3];
+  s.N = g_phys.N; s.pitch = g->pitch; s.m_offset = g->m_offset;
+  s.j1_first = g->j1_first; s.j1_last = g->j1_last; s.j2_first = g->j2_first; s.j2_last = g->j2_last;
+
+  const int block = g_block > 0 ? g_block : 256;
+  if (block % 64 != 0 || block > 256) { fprintf(stderr, "slb_step_fused: block must be 64, 128, 192 or 256\n"); return -1; }
+  int n_chunk = g_n_chunk;
+  if (n_chunk <= 0) {
+    const int  hi = s.j1_last > s.j2_last ? s.j1_last : s.j2_last;
+    const long waves  = (long)hi / (62 * 4) + 1;
+    const long target = 256L * 12L * 4L;               // several rounds of resident waves
+    long split = waves >= target ? 1 : (target + waves - 1) / waves;
+    n_chunk = (int)((s.N + split - 1) / split);
+    if (n_chunk < 16) n_chunk = 16;
+    if (n_chunk > s.N) n_chunk = s.N;
+  }
+  s.n_chunk = n_chunk;
+  return g_variant == 6 ? launch_fused<false>(s, block) : launch_fused<true>(s, block);
 }
 
 void step_on_grid(int blocks, float *a0, float *a_current, float *b_current,

@@ -51,6 +51,7 @@ typedef struct slb_solver {
   int   current, next, current_hs, next_hs;
   float t, frame_time;
   long  steps;
+  int   fused;           /* run_timed / the program use the one-launch step       */
 } slb_solver;
 
 /* Allocate the slab of rank `rank` of `nranks`, build a0 for its columns
@@ -80,6 +81,9 @@ void slb_step_cosines(float t, float c[4]);
 
 /* one loop iteration without display work, single slab (no halo exchange) */
 void slb_solver_step(slb_solver *s);
+
+/* the same iteration as one fused launch (slb_step_fused); single slab */
+void slb_solver_step_fused(slb_solver *s);
 
 /* `steps` iterations bracketed by HIP events on the launch stream; *ms gets the
  * elapsed device time.  Single slab. */

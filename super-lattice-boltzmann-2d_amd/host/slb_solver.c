@@ -203,6 +203,21 @@ void slb_solver_step(slb_solver *s)
   slb_solver_advance(s);
 }
 
+/* one loop iteration as a single fused launch; same results as slb_solver_step */
+void slb_solver_step_fused(slb_solver *s)
+{
+  float c[4];
+  slb_step_cosines(s->t, c);
+  const slb_step_geom g = {s->pitch, s->m_offset, s->main_slab.j_first, s->main_slab.j_last,
+                           s->half_slab.j_first, s->half_slab.j_last};
+  check_sweep(slb_step_fused(&g, s->a0, s->a[s->current], s->b[s->current],
+                             s->a[s->current_hs], s->b[s->current_hs],
+                             s->a[s->next], s->b[s->next], s->a[s->next_hs], s->b[s->next_hs], c),
+              __LINE__);
+  slb_solver_swap(s);
+  slb_solver_advance(s);
+}
+
 int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
 {
   hipStream_t st = (hipStream_t)slb_get_stream();
@@ -210,7 +225,9 @@ int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
   HIP_OK(hipEventRecord(e0, st));
-  for (int i = 0; i < steps; i++) slb_solver_step(s);
+  for (int i = 0; i < steps; i++) {
+    if (s->fused) slb_solver_step_fused(s); else slb_solver_step(s);
+  }
   HIP_OK(hipEventRecord(e1, st));
   HIP_OK(hipEventSynchronize(e1));
   HIP_OK(hipEventElapsedTime(ms, e0, e1));

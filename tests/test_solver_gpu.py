@@ -84,3 +84,37 @@ def test_program_display8_identical(solver_bin, oracle, tmp_path):
     got, exp = (gdir / "frame.data").read_text(), (odir / "frame.data").read_text()
     assert len(exp.splitlines()) == 629 * 62 + 2
     assert got == exp
+
+
+@pytest.mark.parametrize("N,M,B,omega,steps,n_chunk", [
+    (1, 5, 0.5, 3.0, 3, 0), (2, 61, 0.05, 100.0, 6, 0), (7, 300, 0.4, 10.0, 5, 3),
+    (32, 4096, 1.0, 1.0, 20, 0), (33, 1000, 0.5, 30.0, 7, 5), (64, 20001, 0.2, 10.0, 6, 16),
+    (16, 247, 0.3, 10.0, 4, 0), (16, 248, 0.3, 10.0, 4, 8), (16, 249, 0.3, 10.0, 4, 0),
+    (128, 70000, 0.06, 50.0, 3, 32),
+])
+def test_fused_step_bit_exact(slb, oracle, N, M, B, omega, steps, n_chunk):
+    """The one-launch step (both sweeps fused) leaves all nine arrays identical
+    to the oracle's, step after step, including every cell no sweep writes."""
+    p = oracle.make_params(N=N, M=M, B=B, omega=omega)
+    slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    orc = oracle.OracleState(p)
+    sol = slb.Solver()
+    L = slb.lib()
+    try:
+        sol.tiptoe()
+        for variant in (0, 6):
+            L.slb_set_tuning(variant, n_chunk, 0)
+            for _ in range(steps):
+                sol.step_fused()
+            orc.step(steps)
+            _compare_state(sol, orc, M)
+        # mixing the two forms is allowed at any step
+        L.slb_set_tuning(0, 0, 0)
+        sol.step(); sol.step_fused(); sol.step()
+        orc.step(3)
+        _compare_state(sol, orc, M)
+    finally:
+        L.slb_set_tuning(0, 0, 0)
+        sol.close()
+        orc.close()

@@ -32,6 +32,11 @@ CASES = [
     (33, 1000, 0, 3, 7),
     (64, 8191, 0, 3, 16),
     (5, 20000, 0, 3, 0),
+    (2, 61, 0, 4, 0),
+    (9, 255, 0, 4, 4),
+    (33, 1000, 0, 4, 7),
+    (64, 8191, 0, 5, 16),
+    (32, 4096, 0, 5, 0),
 ]
 
 
