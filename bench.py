@@ -26,7 +26,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 N_HARMONICS = 128
 G_GRID_PER_GPU = 1 << 20
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
-BYTES_PER_POINT_SWEEP = 28     # 5 fp32 reads + 2 fp32 writes per lattice point per sweep
+BYTES_PER_POINT_SWEEP = 28     # two-sweep form: 5 fp32 reads + 2 fp32 writes per point per sweep
+BYTES_PER_UPDATE_FUSED = 36    # one-launch step: 5 reads + 4 writes per lattice-point-update
 
 
 def cpu_baseline(n_harm, g_grid, phys, steps):
@@ -57,6 +58,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--n-chunk", type=int, default=0)
     ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--form", choices=("fused", "sweeps"), default="fused",
+                    help="fused: both sweeps of a step in one launch (default); "
+                         "sweeps: the reference's two launches per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
@@ -88,28 +92,30 @@ def main():
     if world == 1:
         sol = slb.Solver(0, 1)
         sol.tiptoe()
-        for _ in range(args.warmup):
-            sol.step()
+        sol.set_fused(args.form == "fused")
+        sol.run_timed(args.warmup)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev_ms = sol.run_timed(args.steps)        # HIP events on the launch stream
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
-        kernel_ms = ev_ms / (2 * args.steps)     # two sweep launches per step, back to back
+        launches_per_step = 1 if args.form == "fused" else 2
+        kernel_ms = ev_ms / (launches_per_step * args.steps)   # launches are back to back
         sol.close()
     else:
         import torch.distributed as dist
         drv = importlib.import_module("super-lattice-boltzmann-2d_amd.dist")
         run = drv.SlabRun(slb, rank, world)
         run.tiptoe()
+        step = run.step_fused if args.form == "fused" else run.step
         for _ in range(args.warmup):
-            run.step()
+            step()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            run.step()
+            step()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -131,25 +137,34 @@ def main():
         "config": {"workload": f"n-harmonics={n_harm} g-grid={g_grid} "
                                f"({args.g_grid_per_gpu} columns per GPU, phi_y slabs) "
                                f"omega=100 B={phys['B']:.6g} dt=0.001, 2 sweeps per step",
-                   "parallelism": f"phi_y-slab x{world}"},
-        "hbm_roofline_frac_per_gpu": 2 * BYTES_PER_POINT_SWEEP * value / world / (HBM_PEAK_GBS * 1e9),
+                   "form": args.form, "parallelism": f"phi_y-slab x{world}"},
+        # whole-job rate against the per-GPU HBM peak, with the bytes this form must move ...
+        "hbm_roofline_frac_per_gpu": (BYTES_PER_UPDATE_FUSED if args.form == "fused" else 2 * BYTES_PER_POINT_SWEEP)
+                                     * value / world / (HBM_PEAK_GBS * 1e9),
+        # ... and with the 56 B/update of the reference's two-sweep formulation, for comparison
+        "equiv_two_sweep_traffic_frac_per_gpu": 2 * BYTES_PER_POINT_SWEEP * value / world / (HBM_PEAK_GBS * 1e9),
     }
     if rank == 0:
         if kernel_ms is not None:
-            # dominant kernel: sweep_kernel (one launch = one sweep of the whole lattice)
+            # dominant kernel; one launch = one step (fused) or one sweep of the whole lattice
             points = n_harm * (g_grid + 0.5)      # main sweep M+1 columns, half sweep M
-            achieved = BYTES_PER_POINT_SWEEP * points / (kernel_ms * 1e-3) / 1e9
+            if args.form == "fused":
+                kernel, alg_bytes = "fused_step_kernel", BYTES_PER_UPDATE_FUSED * points
+            else:
+                kernel, alg_bytes = "sweep_kernel", BYTES_PER_POINT_SWEEP * points
+            achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tfile):
                 with open(tfile) as f:
                     tj = json.load(f)
+                tj = tj.get(args.form, {})
                 if tj.get("n_harmonics") == n_harm and tj.get("g_grid") == g_grid:
                     traffic = tj.get("bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "sweep_kernel", "avg_launch_ms": kernel_ms,
-                               "algorithmic_bytes_per_launch": BYTES_PER_POINT_SWEEP * points}
+                               "kernel": kernel, "avg_launch_ms": kernel_ms,
+                               "algorithmic_bytes_per_launch": alg_bytes}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(n_harm, g_grid, phys, args.cpu_steps)
         print(json.dumps(out), flush=True)

@@ -121,10 +121,11 @@ int slb_step_fused(const slb_step_geom *geom,
                    float *a_next, float *b_next, float *a_next_hs, float *b_next_hs,
                    const float cosines[4]);
 
-/* Gather local column `col` of rows 0..nrows-1 of arrays a and b into
- * buf[0..nrows-1] and buf[nrows..2*nrows-1]; and the inverse scatter. */
-int slb_halo_pack  (const float *a, const float *b, int pitch, int nrows, int col, float *buf);
-int slb_halo_unpack(float *a, float *b, int pitch, int nrows, int col, const float *buf);
+/* Gather local columns col..col+ncols-1 of rows 0..nrows-1 of arrays a and b
+ * into buf (a's columns first, each column contiguous: buf[(q*ncols + c)*nrows + r],
+ * q = 0 for a, 1 for b); and the inverse scatter.  buf holds 2*ncols*nrows floats. */
+int slb_halo_pack  (const float *a, const float *b, int pitch, int nrows, int col, int ncols, float *buf);
+int slb_halo_unpack(float *a, float *b, int pitch, int nrows, int col, int ncols, const float *buf);
 
 /* First stage of av(): the three sums over local columns j_first..j_last
  * (b[1][m]*dPhi, a[0][m]*phi_y(m)*dPhi, a[1][m]*dPhi), terms formed in float as

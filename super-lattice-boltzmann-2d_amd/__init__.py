@@ -51,7 +51,8 @@ class SolverStruct(C.Structure):
                 ("a0", C.c_void_p), ("a", C.c_void_p * 4), ("b", C.c_void_p * 4),
                 ("av_data", C.c_void_p), ("sums", C.c_void_p), ("halo_buf", C.c_void_p),
                 ("current", C.c_int), ("next", C.c_int), ("current_hs", C.c_int), ("next_hs", C.c_int),
-                ("t", C.c_float), ("frame_time", C.c_float), ("steps", C.c_long), ("fused", C.c_int)]
+                ("t", C.c_float), ("frame_time", C.c_float), ("steps", C.c_long), ("fused", C.c_int),
+                ("G", C.c_int)]
 
 
 _lib = None
@@ -77,9 +78,9 @@ def lib():
         L.slb_sweep.restype = i
         L.slb_step_fused.argtypes = [C.POINTER(StepGeom)] + [fp] * 9 + [C.POINTER(C.c_float * 4)]
         L.slb_step_fused.restype = i
-        L.slb_halo_pack.argtypes = [fp, fp, i, i, i, fp]
+        L.slb_halo_pack.argtypes = [fp, fp, i, i, i, i, fp]
         L.slb_halo_pack.restype = i
-        L.slb_halo_unpack.argtypes = [fp, fp, i, i, i, fp]
+        L.slb_halo_unpack.argtypes = [fp, fp, i, i, i, i, fp]
         L.slb_halo_unpack.restype = i
         L.slb_av_partial.argtypes = [C.POINTER(Slab), fp, fp, fp]
         L.slb_av_partial.restype = i
@@ -107,11 +108,13 @@ def lib():
         L.slb_step_cosines.argtypes, L.slb_step_cosines.restype = [f, C.POINTER(C.c_float * 4)], None
         L.slb_solver_step.argtypes, L.slb_solver_step.restype = [C.POINTER(SolverStruct)], None
         L.slb_solver_step_fused.argtypes, L.slb_solver_step_fused.restype = [C.POINTER(SolverStruct)], None
+        L.slb_solver_step_fused_range.argtypes = [C.POINTER(SolverStruct), i, i, C.POINTER(C.c_float * 4)]
+        L.slb_solver_step_fused_range.restype = None
         L.slb_solver_run_timed.argtypes = [C.POINTER(SolverStruct), i, C.POINTER(C.c_float)]
         L.slb_solver_run_timed.restype = i
-        L.slb_solver_halo_pack.argtypes = [C.POINTER(SolverStruct), i, i, fp]
+        L.slb_solver_halo_pack.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
         L.slb_solver_halo_pack.restype = i
-        L.slb_solver_halo_unpack.argtypes = [C.POINTER(SolverStruct), i, i, fp]
+        L.slb_solver_halo_unpack.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
         L.slb_solver_halo_unpack.restype = i
         L.slb_solver_get_rows.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
         L.slb_solver_get_rows.restype = i
@@ -204,13 +207,17 @@ class Solver:
             raise RuntimeError(f"slb_solver_run_timed -> {rc}")
         return ms.value
 
-    def halo_pack(self, which, side, buf_ptr):
-        rc = lib().slb_solver_halo_pack(self._p, which, side, buf_ptr)
+    def step_fused_range(self, j2_first, j2_last, cosines):
+        c = (C.c_float * 4)(*cosines)
+        lib().slb_solver_step_fused_range(self._p, j2_first, j2_last, C.byref(c))
+
+    def halo_pack(self, which, side, ncols, buf_ptr):
+        rc = lib().slb_solver_halo_pack(self._p, which, side, ncols, buf_ptr)
         if rc:
             raise RuntimeError(f"slb_solver_halo_pack -> {rc}")
 
-    def halo_unpack(self, which, side, buf_ptr):
-        rc = lib().slb_solver_halo_unpack(self._p, which, side, buf_ptr)
+    def halo_unpack(self, which, side, ncols, buf_ptr):
+        rc = lib().slb_solver_halo_unpack(self._p, which, side, ncols, buf_ptr)
         if rc:
             raise RuntimeError(f"slb_solver_halo_unpack -> {rc}")
 

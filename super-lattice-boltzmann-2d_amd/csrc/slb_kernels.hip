@@ -397,8 +397,24 @@ __device__ __forceinline__ void widen(const float (&own)[4], float (&e)[6])
   e[5] = from_right_lane(own[0]);
 }
 
-template <bool NT>
-__global__ void __launch_bounds__(256)
+// DIAG: timing-only build of the point update (same memory accesses and lane exchanges,
+// two additions instead of the arithmetic); never used for results.
+template <bool DIAG, class Params>
+__device__ __forceinline__ void point_update_sel(
+    const Params &p, int n, float fn, float mu_part, float mu1_part,
+    float a0v, float ac, float bc, float Ap, float Am, float Bp, float Bm,
+    float dA_lo, float dB_lo, float &a_new, float &b_new)
+{
+  if constexpr (DIAG) {
+    a_new = (a0v + ac) + (Ap + dA_lo) + mu_part * fn;
+    b_new = (bc + Bp) + (Am + Bm) + (dB_lo + mu1_part);
+  } else {
+    point_update(p, n, fn, mu_part, mu1_part, a0v, ac, bc, Ap, Am, Bp, Bm, dA_lo, dB_lo, a_new, b_new);
+  }
+}
+
+template <bool NT, bool PF, int MINW, bool DIAG = false>
+__global__ void __launch_bounds__(256, MINW)
 fused_step_kernel(const FusedArgs p)
 {
   constexpr int V = 4;
@@ -417,78 +433,86 @@ fused_step_kernel(const FusedArgs p)
   const int r_lo  = n0 > 0 ? n0 - 1 : 0;        // first main-sweep row this workgroup forms
   const int r_end = n1;                         // last row needed: n1 (row N comes from memory)
 
-  float mu1a[V], mu1b[V], mu2a[V], mu2b[V];
-  bool  w1[V], w2[V], ok1[V];
-  bool  w1_all = true, w2_all = true, need_old = false;
+  // B*phi_y per column; the field terms (reference: src/boltzmann_c_solver.c:363-364)
+  // are re-formed from it each row, which costs three operations and saves registers
+  float bphi[V];
+  unsigned wmask = 0;                           // bit k: main sweep stores column k; bit 4+k: half sweep;
+                                                // bit 8+k: the main sweep produces column k
+  bool need_old = false;
 #pragma unroll
   for (int k = 0; k < V; k++) {
-    const int   c   = jj + k;
-    const float phi = p.PhiYmin + p.dPhi * (float)(p.m_offset + c - 1);
-    mu1a[k] = ((p.E_dc + p.E_omega * p.c0) + p.B * phi) * p.dt / 2.0f;
-    mu1b[k] = ((p.E_dc + p.E_omega * p.c1) + p.B * phi) * p.dt / 2.0f;
-    mu2a[k] = ((p.E_dc + p.E_omega * p.c2) + p.B * phi) * p.dt / 2.0f;
-    mu2b[k] = ((p.E_dc + p.E_omega * p.c3) + p.B * phi) * p.dt / 2.0f;
-    ok1[k] = c >= p.j1_first && c <= p.j1_last;               // the main sweep produces this column
-    w1[k]  = interior && ok1[k];
-    w2[k]  = interior && c >= p.j2_first && c <= p.j2_last;
-    w1_all = w1_all && w1[k];
-    w2_all = w2_all && w2[k];
+    const int c = jj + k;
+    bphi[k] = p.B * (p.PhiYmin + p.dPhi * (float)(p.m_offset + c - 1));
+    const bool ok1 = c >= p.j1_first && c <= p.j1_last;
+    if (ok1) wmask |= 1u << (8 + k);
+    if (interior && ok1) wmask |= 1u << k;
+    if (interior && c >= p.j2_first && c <= p.j2_last) wmask |= 1u << (4 + k);
     // a column the half-step sweep reads but the main sweep does not write keeps its old value
-    if (!ok1[k] && c >= p.j2_first - 1 && c <= p.j2_last + 1 && c >= 0 && c < p.pitch) need_old = true;
+    if (!ok1 && c >= p.j2_first - 1 && c <= p.j2_last + 1 && c >= 0 && c < p.pitch) need_old = true;
   }
   if (jj != jcl) need_old = false;
+  const bool w1_all = (wmask & 0xfu) == 0xfu, w2_all = (wmask & 0xf0u) == 0xf0u;
+  const float s0 = p.E_dc + p.E_omega * p.c0, s1 = p.E_dc + p.E_omega * p.c1;
+  const float s2 = p.E_dc + p.E_omega * p.c2, s3 = p.E_dc + p.E_omega * p.c3;
 
   const size_t P = (size_t)p.pitch;
 
   // sliding state (rows relative to the main-sweep row r of the current iteration)
-  float dhA_p[V], dhB_p[V];      // half-step lattice, row r-1: X[m+1]-X[m-1]
-  float dhA_c[V], dhB_c[V];      //                    row r
-  float hA_p[V], hB_p[V];        // half-step lattice, row r-1, own columns (centre of half sweep)
+  float hA_p[V], hB_p[V];        // half-step lattice, row r-1, own columns
   float hA_c[V], hB_c[V];        //                    row r
   float a0_p[V];                 // a0 row r-1
   float d1A_pp[V], d1B_pp[V];    // main-sweep output, row r-2: X[m+1]-X[m-1]
   float d1A_p[V], d1B_p[V];      //                    row r-1
 
-  auto load_h = [&](int r, float (&ownA)[V], float (&ownB)[V], float (&dA)[V], float (&dB)[V]) {
+  auto load_h = [&](int r, float (&ownA)[V], float (&ownB)[V]) {
     const float4 va = ld4<NT>(p.a_h + (size_t)r * P, j), vb = ld4<NT>(p.b_h + (size_t)r * P, j);
     ownA[0] = va.x; ownA[1] = va.y; ownA[2] = va.z; ownA[3] = va.w;
     ownB[0] = vb.x; ownB[1] = vb.y; ownB[2] = vb.z; ownB[3] = vb.w;
-    float ea[6], eb[6];
-    widen(ownA, ea); widen(ownB, eb);
-#pragma unroll
-    for (int k = 0; k < V; k++) { dA[k] = ea[k + 2] - ea[k]; dB[k] = eb[k + 2] - eb[k]; }
   };
 
 #pragma unroll
   for (int k = 0; k < V; k++) {
-    dhA_p[k] = dhB_p[k] = 0.0f; hA_p[k] = hB_p[k] = 0.0f; a0_p[k] = 0.0f;
+    hA_p[k] = hB_p[k] = 0.0f; a0_p[k] = 0.0f;
     d1A_pp[k] = d1B_pp[k] = d1A_p[k] = d1B_p[k] = 0.0f;
   }
-  if (r_lo >= 1) load_h(r_lo - 1, hA_p, hB_p, dhA_p, dhB_p);
-  load_h(r_lo, hA_c, hB_c, dhA_c, dhB_c);
+  if (r_lo >= 1) load_h(r_lo - 1, hA_p, hB_p);
+  load_h(r_lo, hA_c, hB_c);
+
+  // the five input rows of main-sweep row r: a0, a, b at row r; half-step lattice at row r+1
+  struct RowIn { float a0[V], ac[V], bc[V], hA[V], hB[V]; };
+  auto load_row = [&](int r, RowIn &in) {
+    const size_t row = (size_t)r * P;
+    const float4 v0 = ld4<NT>(p.a0 + row, j), v1 = ld4<NT>(p.a_c + row, j), v2 = ld4<NT>(p.b_c + row, j);
+    const float4 va = ld4<NT>(p.a_h + row + P, j), vb = ld4<NT>(p.b_h + row + P, j);
+    in.a0[0] = v0.x; in.a0[1] = v0.y; in.a0[2] = v0.z; in.a0[3] = v0.w;
+    in.ac[0] = v1.x; in.ac[1] = v1.y; in.ac[2] = v1.z; in.ac[3] = v1.w;
+    in.bc[0] = v2.x; in.bc[1] = v2.y; in.bc[2] = v2.z; in.bc[3] = v2.w;
+    in.hA[0] = va.x; in.hA[1] = va.y; in.hA[2] = va.z; in.hA[3] = va.w;
+    in.hB[0] = vb.x; in.hB[1] = vb.y; in.hB[2] = vb.z; in.hB[3] = vb.w;
+  };
+  RowIn cur = {}, nxt = {};
+  if constexpr (PF) { if (r_lo < p.N) load_row(r_lo, cur); }
 
   for (int r = r_lo; r <= r_end; r++) {
     float o1A[V], o1B[V];          // main-sweep output row r, own columns
-    float a0_r[V];
-    float hA_n[V], hB_n[V], dhA_n[V], dhB_n[V];
     const size_t row = (size_t)r * P;
+    if constexpr (PF) {
+      // next row's loads go out before this row is computed
+      if (r + 1 <= r_end && r + 1 < p.N) load_row(r + 1, nxt);
+    }
     if (r < p.N) {
       // ---- main sweep, row r ----
-      const float4 v0 = ld4<NT>(p.a0 + row, j), v1 = ld4<NT>(p.a_c + row, j), v2 = ld4<NT>(p.b_c + row, j);
-      const float ac[V] = {v1.x, v1.y, v1.z, v1.w}, bc[V] = {v2.x, v2.y, v2.z, v2.w};
-      a0_r[0] = v0.x; a0_r[1] = v0.y; a0_r[2] = v0.z; a0_r[3] = v0.w;
-      const float4 va = ld4<NT>(p.a_h + row + P, j), vb = ld4<NT>(p.b_h + row + P, j);
-      hA_n[0] = va.x; hA_n[1] = va.y; hA_n[2] = va.z; hA_n[3] = va.w;
-      hB_n[0] = vb.x; hB_n[1] = vb.y; hB_n[2] = vb.z; hB_n[3] = vb.w;
-      float ea[6], eb[6];
-      widen(hA_n, ea); widen(hB_n, eb);
+      if constexpr (!PF) load_row(r, cur);
+      float ea[6], eb[6], la[6], lb[6];
+      widen(cur.hA, ea); widen(cur.hB, eb);       // row r+1 with its m+-1 neighbours
+      widen(hA_p, la);   widen(hB_p, lb);         // row r-1 likewise
       const float fr = (float)r;
 #pragma unroll
       for (int k = 0; k < V; k++) {
-        point_update(p, r, fr, mu1a[k], mu1b[k], a0_r[k], ac[k], bc[k],
-                     ea[k + 2], ea[k], eb[k + 2], eb[k], dhA_p[k], dhB_p[k], o1A[k], o1B[k]);
-        dhA_n[k] = ea[k + 2] - ea[k];
-        dhB_n[k] = eb[k + 2] - eb[k];
+        const float mu_a = (s0 + bphi[k]) * p.dt / 2.0f, mu_b = (s1 + bphi[k]) * p.dt / 2.0f;
+        point_update_sel<DIAG>(p, r, fr, mu_a, mu_b, cur.a0[k], cur.ac[k], cur.bc[k],
+                     ea[k + 2], ea[k], eb[k + 2], eb[k], la[k + 2] - la[k], lb[k + 2] - lb[k],
+                     o1A[k], o1B[k]);
       }
       if (r >= n0 && r < n1) {
         if (w1_all) {
@@ -497,7 +521,7 @@ fused_step_kernel(const FusedArgs p)
         } else {
 #pragma unroll
           for (int k = 0; k < V; k++) {
-            if (w1[k]) {
+            if (wmask & (1u << k)) {
               p.a_n[row + j + k] = o1A[k];
               if (r > 0) p.b_n[row + j + k] = o1B[k];
             }
@@ -512,7 +536,7 @@ fused_step_kernel(const FusedArgs p)
         const float olda[V] = {oa.x, oa.y, oa.z, oa.w}, oldb[V] = {ob.x, ob.y, ob.z, ob.w};
 #pragma unroll
         for (int k = 0; k < V; k++) {
-          if (!ok1[k]) { o1A[k] = olda[k]; o1B[k] = oldb[k]; }
+          if (!(wmask & (1u << (8 + k)))) { o1A[k] = olda[k]; o1B[k] = oldb[k]; }
         }
       }
     } else {
@@ -521,8 +545,6 @@ fused_step_kernel(const FusedArgs p)
       const float4 ob = *reinterpret_cast<const float4 *>(p.b_n + row + j);
       o1A[0] = oa.x; o1A[1] = oa.y; o1A[2] = oa.z; o1A[3] = oa.w;
       o1B[0] = ob.x; o1B[1] = ob.y; o1B[2] = ob.z; o1B[3] = ob.w;
-#pragma unroll
-      for (int k = 0; k < V; k++) { a0_r[k] = 0.0f; hA_n[k] = hB_n[k] = dhA_n[k] = dhB_n[k] = 0.0f; }
     }
 
     // ---- half-step sweep, row r-1, from main rows r (here) and r-2 (differences kept) ----
@@ -534,16 +556,18 @@ fused_step_kernel(const FusedArgs p)
       const float fn = (float)n;
       const size_t rown = (size_t)n * P;
 #pragma unroll
-      for (int k = 0; k < V; k++)
-        point_update(p, n, fn, mu2a[k], mu2b[k], a0_p[k], hA_p[k], hB_p[k],
+      for (int k = 0; k < V; k++) {
+        const float mu_a = (s2 + bphi[k]) * p.dt / 2.0f, mu_b = (s3 + bphi[k]) * p.dt / 2.0f;
+        point_update_sel<DIAG>(p, n, fn, mu_a, mu_b, a0_p[k], hA_p[k], hB_p[k],
                      e1a[k + 2], e1a[k], e1b[k + 2], e1b[k], d1A_pp[k], d1B_pp[k], o2A[k], o2B[k]);
+      }
       if (w2_all) {
         st4<NT>(p.a_hn + rown, j, o2A);
         if (n > 0) st4<NT>(p.b_hn + rown, j, o2B);
       } else {
 #pragma unroll
         for (int k = 0; k < V; k++) {
-          if (w2[k]) {
+          if (wmask & (1u << (4 + k))) {
             p.a_hn[rown + j + k] = o2A[k];
             if (n > 0) p.b_hn[rown + j + k] = o2B[k];
           }
@@ -555,31 +579,33 @@ fused_step_kernel(const FusedArgs p)
     for (int k = 0; k < V; k++) {
       d1A_pp[k] = d1A_p[k];               d1B_pp[k] = d1B_p[k];
       d1A_p[k]  = e1a[k + 2] - e1a[k];    d1B_p[k]  = e1b[k + 2] - e1b[k];
-      dhA_p[k] = dhA_c[k]; dhB_p[k] = dhB_c[k]; dhA_c[k] = dhA_n[k]; dhB_c[k] = dhB_n[k];
-      hA_p[k] = hA_c[k];   hB_p[k] = hB_c[k];   hA_c[k] = hA_n[k];   hB_c[k] = hB_n[k];
-      a0_p[k] = a0_r[k];
+      hA_p[k] = hA_c[k];   hB_p[k] = hB_c[k];
+      hA_c[k] = cur.hA[k]; hB_c[k] = cur.hB[k];
+      a0_p[k] = cur.a0[k];
     }
+    if constexpr (PF) cur = nxt;
   }
 }
 
 // ---------------------------------------------------------------------------
 // halo movers: one column of rows 0..nrows-1 of two arrays <-> contiguous buffer
 // ---------------------------------------------------------------------------
-__global__ void halo_pack_kernel(const float *a, const float *b, int pitch, int nrows, int col, float *buf)
+// buf[(q*ncols + c)*nrows + r] <-> array q (0 = a, 1 = b), row r, column col + c
+__global__ void halo_pack_kernel(const float *a, const float *b, int pitch, int nrows, int col, int ncols, float *buf)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * nrows) return;
-  const float *src = i < nrows ? a : b;
-  const int r = i < nrows ? i : i - nrows;
-  buf[i] = src[(size_t)r * pitch + col];
+  if (i >= 2 * ncols * nrows) return;
+  const int r = i % nrows, qc = i / nrows, c = qc % ncols;
+  const float *src = qc < ncols ? a : b;
+  buf[i] = src[(size_t)r * pitch + col + c];
 }
-__global__ void halo_unpack_kernel(float *a, float *b, int pitch, int nrows, int col, const float *buf)
+__global__ void halo_unpack_kernel(float *a, float *b, int pitch, int nrows, int col, int ncols, const float *buf)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * nrows) return;
-  float *dst = i < nrows ? a : b;
-  const int r = i < nrows ? i : i - nrows;
-  dst[(size_t)r * pitch + col] = buf[i];
+  if (i >= 2 * ncols * nrows) return;
+  const int r = i % nrows, qc = i / nrows, c = qc % ncols;
+  float *dst = qc < ncols ? a : b;
+  dst[(size_t)r * pitch + col + c] = buf[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -735,7 +761,7 @@ int launch_pipe(SweepArgs &args, int block)
   return (int)hipGetLastError();
 }
 
-template <bool NT>
+template <bool NT, bool PF, int MINW, bool DIAG = false>
 int launch_fused(FusedArgs &args, int block)
 {
   const int lo = args.j1_first < args.j2_first ? args.j1_first : args.j2_first;
@@ -745,7 +771,7 @@ int launch_fused(FusedArgs &args, int block)
   const int waves = (hi + 1 - args.jj0 + per_wave - 1) / per_wave;
   const int wpb = block / 64;
   dim3 grid((waves + wpb - 1) / wpb, (args.N + args.n_chunk - 1) / args.n_chunk);
-  hipLaunchKernelGGL((fused_step_kernel<NT>), grid, dim3(block), 0, g_stream, args);
+  hipLaunchKernelGGL((fused_step_kernel<NT, PF, MINW, DIAG>), grid, dim3(block), 0, g_stream, args);
   return (int)hipGetLastError();
 }
 
@@ -886,7 +912,17 @@ int slb_step_fused(const slb_step_geom *g,
     if (n_chunk > s.N) n_chunk = s.N;
   }
   s.n_chunk = n_chunk;
-  return g_variant == 6 ? launch_fused<false>(s, block) : launch_fused<true>(s, block);
+  switch (g_variant) {
+    case 6:  return launch_fused<false, false, 4>(s, block);
+    case 7:  return launch_fused<true, false, 4>(s, block);
+    case 8:  return launch_fused<false, true, 3>(s, block);
+    case 9:  return launch_fused<true, true, 3>(s, block);
+    case 10: return launch_fused<false, false, 5>(s, block);
+    case 11: return launch_fused<true, false, 5>(s, block);
+    case 12: return launch_fused<false, false, 6>(s, block);
+    case 99: return launch_fused<false, false, 4, true>(s, block);   // timing only, wrong results
+    default: return launch_fused<false, false, 4>(s, block);
+  }
 }
 
 void step_on_grid(int blocks, float *a0, float *a_current, float *b_current,
@@ -916,19 +952,19 @@ void step_on_half_grid(int blocks, float *a0, float *a_current, float *b_current
   if (rc < 0) exit(EXIT_FAILURE);
 }
 
-int slb_halo_pack(const float *a, const float *b, int pitch, int nrows, int col, float *buf)
+int slb_halo_pack(const float *a, const float *b, int pitch, int nrows, int col, int ncols, float *buf)
 {
-  if (nrows < 1 || col < 0 || col >= pitch) return -1;
-  const int n = 2 * nrows;
-  hipLaunchKernelGGL(halo_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, a, b, pitch, nrows, col, buf);
+  if (nrows < 1 || ncols < 1 || col < 0 || col + ncols > pitch) return -1;
+  const int n = 2 * ncols * nrows;
+  hipLaunchKernelGGL(halo_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, a, b, pitch, nrows, col, ncols, buf);
   return (int)hipGetLastError();
 }
 
-int slb_halo_unpack(float *a, float *b, int pitch, int nrows, int col, const float *buf)
+int slb_halo_unpack(float *a, float *b, int pitch, int nrows, int col, int ncols, const float *buf)
 {
-  if (nrows < 1 || col < 0 || col >= pitch) return -1;
-  const int n = 2 * nrows;
-  hipLaunchKernelGGL(halo_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, a, b, pitch, nrows, col, buf);
+  if (nrows < 1 || ncols < 1 || col < 0 || col + ncols > pitch) return -1;
+  const int n = 2 * ncols * nrows;
+  hipLaunchKernelGGL(halo_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, a, b, pitch, nrows, col, ncols, buf);
   return (int)hipGetLastError();
 }
 

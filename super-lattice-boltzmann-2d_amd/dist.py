@@ -3,17 +3,25 @@ with torch.distributed point-to-point operations (backend "nccl" = RCCL over
 xGMI on MI355X; "gloo" for CPU rehearsals).
 
 The reference is single-GPU; this driver is additive.  Coupling along phi_y is
-+-1 column on the stencil lattice of each sweep (reference:
-src/boltzmann_c_solver.c:370-372), so before a sweep each slab needs one ghost
-column per side of the lattice that sweep reads as stencil -- which is the
-lattice the PREVIOUS sweep wrote.  Each sweep therefore runs as
++-1 column on the lattice a sweep reads as stencil (reference:
+src/boltzmann_c_solver.c:370-372), and that lattice is the one the PREVIOUS
+sweep wrote.  Ranks form a non-periodic chain: rank r talks to r-1 and r+1.
+A slab keeps G = 2 ghost columns per side; owned columns are G .. G+W-1.
 
-    edge columns -> pack -> start send/recv -> interior columns -> wait -> unpack
+Two step forms, bit-identical to each other and to a single-domain run:
 
-so the exchange of the freshly written edge columns travels while the interior
-is being updated.  Ranks form a non-periodic chain: rank r talks to r-1 and r+1.
+* ``step()``  -- the reference's two sweeps, each as
+      edge columns -> pack 1 column -> send/recv -> interior columns -> wait -> unpack
+  (two exchanges per step).
+* ``step_fused()`` -- both sweeps in one launch per column range.  A slab forms
+  the main sweep one column into its ghost zone itself (same inputs, same bits as
+  the owner), so only the NEW half-step lattice travels: 2 columns per side,
+  ONE exchange per step:
+      edge ranges -> pack 2 columns -> send/recv -> interior range -> wait -> unpack
+
+Either way the ~1-4 KB messages travel while the interior is being updated.
 All arithmetic stays in the engine (the HIP kernels); this file only orders
-launches and moves 2*(N+1) floats per side.
+launches and moves 2*ncols*(N+1) floats per side.
 """
 import torch
 import torch.distributed as dist
@@ -27,12 +35,12 @@ class HipEngine:
         self.sol = slb.Solver(rank, world)
         s = self.sol.s
         self.rank, self.world = rank, world
-        self.N, self.W = s.N, s.W
+        self.N, self.W, self.G = s.N, s.W, s.G
         self.j_last_main, self.j_last_half = s.main_slab.j_last, s.half_slab.j_last
         self.device = torch.device("cuda", torch.cuda.current_device())
 
-    def new_buffer(self):
-        return torch.empty(2 * (self.N + 1), dtype=torch.float32, device=self.device)
+    def new_buffer(self, ncols):
+        return torch.empty(2 * ncols * (self.N + 1), dtype=torch.float32, device=self.device)
 
     def tiptoe(self):
         self.sol.tiptoe()
@@ -43,11 +51,14 @@ class HipEngine:
     def sweep_range(self, lattice, j_first, j_last, c0, c1):
         self.sol.sweep_range(lattice, j_first, j_last, c0, c1)
 
-    def pack(self, which, side, buf):
-        self.sol.halo_pack(which, side, buf.data_ptr())
+    def step_fused_range(self, j2_first, j2_last, cosines):
+        self.sol.step_fused_range(j2_first, j2_last, cosines)
 
-    def unpack(self, which, side, buf):
-        self.sol.halo_unpack(which, side, buf.data_ptr())
+    def pack(self, which, side, ncols, buf):
+        self.sol.halo_pack(which, side, ncols, buf.data_ptr())
+
+    def unpack(self, which, side, ncols, buf):
+        self.sol.halo_unpack(which, side, ncols, buf.data_ptr())
 
     def swap(self):
         self.sol.swap()
@@ -68,67 +79,90 @@ class SlabRun:
         self.eng = engine if engine is not None else HipEngine(slb, rank, world)
         self.left = rank - 1 if rank > 0 else None
         self.right = rank + 1 if rank < world - 1 else None
-        self.send = [self.eng.new_buffer(), self.eng.new_buffer()]
-        self.recv = [self.eng.new_buffer(), self.eng.new_buffer()]
+        # [ncols][side] send / receive buffers
+        self.send = {n: [self.eng.new_buffer(n), self.eng.new_buffer(n)] for n in (1, 2)}
+        self.recv = {n: [self.eng.new_buffer(n), self.eng.new_buffer(n)] for n in (1, 2)}
         self.cpu_staging = dist.is_initialized() and dist.get_backend(group) == "gloo"
 
     # -- halo exchange of lattice `which` (see slb_solver_halo_pack) ----------
-    def _start_exchange(self, which):
+    def _start_exchange(self, which, ncols):
         ops, staged = [], []
         for side, peer in ((0, self.left), (1, self.right)):
             if peer is None:
                 continue
-            self.eng.pack(which, side, self.send[side])
-            if self.cpu_staging and self.send[side].is_cuda:
-                s_buf, r_buf = self.send[side].cpu(), torch.empty_like(self.recv[side], device="cpu")
+            s_dev, r_dev = self.send[ncols][side], self.recv[ncols][side]
+            self.eng.pack(which, side, ncols, s_dev)
+            if self.cpu_staging and s_dev.is_cuda:
+                s_buf, r_buf = s_dev.cpu(), torch.empty_like(r_dev, device="cpu")
                 staged.append((side, r_buf))
             else:
-                s_buf, r_buf = self.send[side], self.recv[side]
+                s_buf, r_buf = s_dev, r_dev
             ops.append(dist.P2POp(dist.isend, s_buf, peer, group=self.group))
             ops.append(dist.P2POp(dist.irecv, r_buf, peer, group=self.group))
         reqs = dist.batch_isend_irecv(ops) if ops else []
-        return reqs, staged
+        return reqs, staged, ncols
 
     def _finish_exchange(self, which, pending):
-        reqs, staged = pending
+        reqs, staged, ncols = pending
         for r in reqs:
             r.wait()
         for side, r_buf in staged:
-            self.recv[side].copy_(r_buf)
+            self.recv[ncols][side].copy_(r_buf)
         for side, peer in ((0, self.left), (1, self.right)):
             if peer is not None:
-                self.eng.unpack(which, side, self.recv[side])
+                self.eng.unpack(which, side, ncols, self.recv[ncols][side])
 
-    def exchange(self, which):
-        self._finish_exchange(which, self._start_exchange(which))
+    def exchange(self, which, ncols):
+        self._finish_exchange(which, self._start_exchange(which, ncols))
 
-    # -- one sweep: edges first, exchange its output while the interior runs --
-    def _sweep(self, lattice, which_out, c0, c1):
+    # -- sweep-by-sweep form ---------------------------------------------------
+    def _sweep(self, lattice, which_out, ncols, c0, c1):
         e = self.eng
+        first, last_owned = e.G, e.G + e.W - 1
         j_last = e.j_last_main if lattice == 0 else e.j_last_half
-        lo, hi = 1, j_last
+        lo, hi = first, j_last
         if self.left is not None:
-            e.sweep_range(lattice, 1, 1, c0, c1)
-            lo = 2
+            e.sweep_range(lattice, first, first + ncols - 1, c0, c1)
+            lo = first + ncols
         if self.right is not None:
-            e.sweep_range(lattice, e.W, e.W, c0, c1)
-            hi = e.W - 1
-        pending = self._start_exchange(which_out)
+            e.sweep_range(lattice, last_owned - ncols + 1, last_owned, c0, c1)
+            hi = last_owned - ncols
+        pending = self._start_exchange(which_out, ncols)
         e.sweep_range(lattice, lo, hi, c0, c1)
         self._finish_exchange(which_out, pending)
 
     def tiptoe(self):
         """First half step; afterwards the half-step lattice's ghost columns are
-        brought up to date so that step() can start with a main sweep."""
+        brought up to date (both of them, so that either step form can follow)."""
         self.eng.tiptoe()
-        self.exchange(0)
+        self.exchange(0, 2)
 
     def step(self):
         c = self.eng.cosines()
-        self._sweep(0, 1, c[0], c[1])      # main lattice: writes a/b[next], ships its edges
-        self._sweep(1, 2, c[2], c[3])      # half-step lattice: writes a/b[next_hs], ships its edges
+        self._sweep(0, 1, 1, c[0], c[1])   # main lattice: writes a/b[next], ships 1 edge column
+        # half-step lattice: writes a/b[next_hs]; 2 edge columns travel so that a
+        # one-launch step may follow a two-sweep step
+        self._sweep(1, 2, 2, c[2], c[3])
         self.eng.swap()
         self.eng.advance()
+
+    # -- one-launch form -------------------------------------------------------
+    def step_fused(self):
+        e = self.eng
+        c = e.cosines()
+        first, last_owned = e.G, e.G + e.W - 1
+        lo, hi = first, last_owned
+        if self.left is not None:
+            e.step_fused_range(first, first + 1, c)
+            lo = first + 2
+        if self.right is not None:
+            e.step_fused_range(last_owned - 1, last_owned, c)
+            hi = last_owned - 2
+        pending = self._start_exchange(2, 2)         # new half-step lattice, 2 columns per side
+        e.step_fused_range(lo, hi, c)
+        self._finish_exchange(2, pending)
+        e.swap()
+        e.advance()
 
     def close(self):
         self.eng.close()

@@ -52,6 +52,7 @@ typedef struct slb_solver {
   float t, frame_time;
   long  steps;
   int   fused;           /* run_timed / the program use the one-launch step       */
+  int   G;               /* ghost columns per side; owned columns are G..G+W-1    */
 } slb_solver;
 
 /* Allocate the slab of rank `rank` of `nranks`, build a0 for its columns
@@ -84,6 +85,9 @@ void slb_solver_step(slb_solver *s);
 
 /* the same iteration as one fused launch (slb_step_fused); single slab */
 void slb_solver_step_fused(slb_solver *s);
+/* the fused step for half-step-lattice columns j2_first..j2_last only (no swap,
+ * no time advance); c = slb_step_cosines() of the current time */
+void slb_solver_step_fused_range(slb_solver *s, int j2_first, int j2_last, const float c[4]);
 
 /* `steps` iterations bracketed by HIP events on the launch stream; *ms gets the
  * elapsed device time.  Single slab. */
@@ -93,11 +97,12 @@ int slb_solver_run_timed(slb_solver *s, int steps, float *ms);
  * which: 0 = a/b[current_hs] (stencil of the main sweep),
  *        1 = a/b[next]       (output of the main sweep, stencil of the half sweep),
  *        2 = a/b[next_hs]    (output of the half sweep, next step's current_hs).
- * side:  0 = left neighbour (send my column 1, receive into column 0),
- *        1 = right neighbour (send my column W, receive into column W+1).
- * buf holds 2*(N+1) floats (device). */
-int slb_solver_halo_pack  (slb_solver *s, int which, int side, float *buf);
-int slb_solver_halo_unpack(slb_solver *s, int which, int side, const float *buf);
+ * side:  0 = left neighbour (send my first ncols owned columns, receive into the
+ *            ncols ghost columns left of them), 1 = right neighbour likewise.
+ * ncols: 1 for the sweep-by-sweep form, 2 for the one-launch step.
+ * buf holds 2*ncols*(N+1) floats (device). */
+int slb_solver_halo_pack  (slb_solver *s, int which, int side, int ncols, float *buf);
+int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const float *buf);
 
 /* copy rows [row0, row0+nrows) of device array `arr` (0 = a0, 1..4 = a[0..3],
  * 5..8 = b[0..3]) into dst as nrows x pitch floats */

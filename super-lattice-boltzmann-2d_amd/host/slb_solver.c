@@ -69,18 +69,29 @@ slb_solver *slb_solver_create(int rank, int nranks)
   s->N = host_N; s->M = host_M; s->rank = rank; s->nranks = nranks;
 
   /* columns 1..M are dealt out in contiguous runs; the last slab also carries
-   * column M+1 of the main lattice and the boundary column M+2 */
+   * column M+1 of the main lattice and the boundary column M+2.  A slab keeps
+   * G ghost columns per side: 1 for a single slab (the reference layout, the
+   * ghosts are the boundary columns 0 and M+2), 2 when there are neighbours, so
+   * that the one-launch step can recompute the main sweep one column into the
+   * ghost zone and needs one exchange per step. */
   const int base = host_M / nranks, rem = host_M % nranks;
   s->W = base + (rank < rem ? 1 : 0);
+  s->G = nranks == 1 ? 1 : 2;
+  if (nranks > 1 && s->W < 4) {
+    fprintf(stderr, "slb_solver_create: slabs need at least 4 columns each\n");
+    free(s);
+    return NULL;
+  }
   const int first = 1 + rank * base + (rank < rem ? rank : rem);
-  s->m_offset = first - 1;
-  const int cols = s->W + 3;
+  s->m_offset = first - s->G;
+  const int cols = s->W + 2 * s->G + 1;
   s->pitch = nranks == 1 ? PADDED_MSIZE : (cols + 31) / 32 * 32;
 
   const int last = rank == nranks - 1;
-  s->main_slab = (slb_slab){s->pitch, s->m_offset, 1, s->W + (last ? 1 : 0)};
-  s->half_slab = (slb_slab){s->pitch, s->m_offset, 1, s->W};
-  s->av_slab   = (slb_slab){s->pitch, s->m_offset, 1, s->W};
+  const int G = s->G;
+  s->main_slab = (slb_slab){s->pitch, s->m_offset, G, G + s->W - 1 + (last ? 1 : 0)};
+  s->half_slab = (slb_slab){s->pitch, s->m_offset, G, G + s->W - 1};
+  s->av_slab   = (slb_slab){s->pitch, s->m_offset, G, G + s->W - 1};
 
   const size_t cells = (size_t)(s->N + 1) * (size_t)s->pitch;
   const size_t bytes = cells * sizeof(float);
@@ -101,7 +112,7 @@ slb_solver *slb_solver_create(int rank, int nranks)
   HIP_OK(hipMalloc((void **)&s->av_data, 6 * sizeof(float)));
   HIP_OK(hipMemset(s->av_data, 0, 6 * sizeof(float)));
   HIP_OK(hipMalloc((void **)&s->sums, 4 * sizeof(double)));
-  HIP_OK(hipMalloc((void **)&s->halo_buf, (size_t)8 * (s->N + 1) * sizeof(float)));
+  HIP_OK(hipMalloc((void **)&s->halo_buf, (size_t)16 * (s->N + 1) * sizeof(float)));
   HIP_OK(hipDeviceSynchronize());
 
   s->current = 0; s->next = 1; s->current_hs = 2; s->next_hs = 3;
@@ -203,17 +214,35 @@ void slb_solver_step(slb_solver *s)
   slb_solver_advance(s);
 }
 
+/* Both sweeps in one launch for half-step-lattice columns j2_first..j2_last
+ * (clipped to the slab's own); the main sweep is formed one column further out
+ * on each side, as far as this slab may form it: up to the ghost column next to
+ * a neighbour (recomputed here, bit-identical to the neighbour's own value),
+ * not into a global boundary column.  Main-sweep columns outside this launch
+ * are taken from memory, so a step may be issued as several column ranges. */
+void slb_solver_step_fused_range(slb_solver *s, int j2_first, int j2_last, const float c[4])
+{
+  const int G = s->G;
+  const int j1_lo = s->rank == 0 ? G : G - 1, j1_hi = G + s->W;
+  slb_step_geom g;
+  g.pitch = s->pitch; g.m_offset = s->m_offset;
+  g.j2_first = j2_first > s->half_slab.j_first ? j2_first : s->half_slab.j_first;
+  g.j2_last  = j2_last  < s->half_slab.j_last  ? j2_last  : s->half_slab.j_last;
+  if (g.j2_last < g.j2_first) return;
+  g.j1_first = g.j2_first - 1 > j1_lo ? g.j2_first - 1 : j1_lo;
+  g.j1_last  = g.j2_last + 1 < j1_hi ? g.j2_last + 1 : j1_hi;
+  check_sweep(slb_step_fused(&g, s->a0, s->a[s->current], s->b[s->current],
+                             s->a[s->current_hs], s->b[s->current_hs],
+                             s->a[s->next], s->b[s->next], s->a[s->next_hs], s->b[s->next_hs], c),
+              __LINE__);
+}
+
 /* one loop iteration as a single fused launch; same results as slb_solver_step */
 void slb_solver_step_fused(slb_solver *s)
 {
   float c[4];
   slb_step_cosines(s->t, c);
-  const slb_step_geom g = {s->pitch, s->m_offset, s->main_slab.j_first, s->main_slab.j_last,
-                           s->half_slab.j_first, s->half_slab.j_last};
-  check_sweep(slb_step_fused(&g, s->a0, s->a[s->current], s->b[s->current],
-                             s->a[s->current_hs], s->b[s->current_hs],
-                             s->a[s->next], s->b[s->next], s->a[s->next_hs], s->b[s->next_hs], c),
-              __LINE__);
+  slb_solver_step_fused_range(s, s->half_slab.j_first, s->half_slab.j_last, c);
   slb_solver_swap(s);
   slb_solver_advance(s);
 }
@@ -241,18 +270,20 @@ static int halo_array(const slb_solver *s, int which)
   return which == 0 ? s->current_hs : (which == 1 ? s->next : s->next_hs);
 }
 
-int slb_solver_halo_pack(slb_solver *s, int which, int side, float *buf)
+int slb_solver_halo_pack(slb_solver *s, int which, int side, int ncols, float *buf)
 {
   const int idx = halo_array(s, which);
-  const int col = side == 0 ? 1 : s->W;
-  return slb_halo_pack(s->a[idx], s->b[idx], s->pitch, s->N + 1, col, buf);
+  if (ncols < 1 || ncols > s->G) return -1;
+  const int col = side == 0 ? s->G : s->G + s->W - ncols;       /* my outermost owned columns */
+  return slb_halo_pack(s->a[idx], s->b[idx], s->pitch, s->N + 1, col, ncols, buf);
 }
 
-int slb_solver_halo_unpack(slb_solver *s, int which, int side, const float *buf)
+int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const float *buf)
 {
   const int idx = halo_array(s, which);
-  const int col = side == 0 ? 0 : s->W + 1;
-  return slb_halo_unpack(s->a[idx], s->b[idx], s->pitch, s->N + 1, col, buf);
+  if (ncols < 1 || ncols > s->G) return -1;
+  const int col = side == 0 ? s->G - ncols : s->G + s->W;       /* the ghost columns next to them */
+  return slb_halo_unpack(s->a[idx], s->b[idx], s->pitch, s->N + 1, col, ncols, buf);
 }
 
 int slb_solver_get_rows(slb_solver *s, int arr, int row0, int nrows, float *dst)

@@ -14,12 +14,12 @@ PKG = "super-lattice-boltzmann-2d_amd"
 
 
 def slab_columns(M, rank, world):
-    """(W, m_offset): owned columns and global index of local column 0
+    """(W, first): number of owned columns and global index of the first one
     (same dealing-out rule as slb_solver_create)."""
     base, rem = divmod(M, world)
     W = base + (1 if rank < rem else 0)
     first = 1 + rank * base + min(rank, rem)
-    return W, first - 1
+    return W, first
 
 
 class OracleEngine:
@@ -28,23 +28,31 @@ class OracleEngine:
         self.torch = torch
         self.ob, self.p, self.rank, self.world = ob, p, rank, world
         self.N = p.N
-        self.W, self.m_offset = slab_columns(p.M, rank, world)
-        self.pitch = self.W + 3
+        self.W, first = slab_columns(p.M, rank, world)
+        self.G = 1 if world == 1 else 2
+        G = self.G
+        self.m_offset = first - G
+        self.pitch = self.W + 2 * G + 1
         last = rank == world - 1
-        self.j_last_main = self.W + (1 if last else 0)
-        self.j_last_half = self.W
+        self.j_last_main = G + self.W - 1 + (1 if last else 0)
+        self.j_last_half = G + self.W - 1
         rows = p.N + 1
         a0_full = np.zeros((rows, p.M + 3), dtype=np.float32)
         ob.lib().orc_init_a0(C.byref(p), a0_full)
-        self.a0 = np.ascontiguousarray(a0_full[:, self.m_offset:self.m_offset + self.pitch])
+        # local column j is global column m_offset + j; columns outside 0..M+2 do not exist
+        self.a0 = np.zeros((rows, self.pitch), dtype=np.float32)
+        for j in range(self.pitch):
+            m = self.m_offset + j
+            if 0 <= m <= p.M + 2:
+                self.a0[:, j] = a0_full[:, m]
         self.a = [np.zeros((rows, self.pitch), dtype=np.float32) for _ in range(4)]
         self.b = [np.zeros((rows, self.pitch), dtype=np.float32) for _ in range(4)]
         self.a[0][:] = self.a0
         self.cur, self.nxt, self.cur_hs, self.nxt_hs = 0, 1, 2, 3
         self.t = np.float32(0)
 
-    def new_buffer(self):
-        return self.torch.empty(2 * (self.N + 1), dtype=self.torch.float32)
+    def new_buffer(self, ncols):
+        return self.torch.empty(2 * ncols * (self.N + 1), dtype=self.torch.float32)
 
     def _sweep(self, j0, j1, ac, bc, a_s, b_s, ao, bo, c0, c1):
         if j1 >= j0:
@@ -52,7 +60,7 @@ class OracleEngine:
 
     def tiptoe(self):
         c1 = np.float32(np.cos(np.float64(np.float32(self.p.omega) * np.float32(self.p.dt))))
-        self._sweep(1, self.j_last_main, self.a[0], self.b[0], self.a[0], self.b[0],
+        self._sweep(self.G, self.j_last_main, self.a[0], self.b[0], self.a[0], self.b[0],
                     self.a[2], self.b[2], np.float32(1), c1)
 
     def cosines(self):
@@ -65,25 +73,41 @@ class OracleEngine:
     def sweep_range(self, lattice, j_first, j_last, c0, c1):
         if lattice == 0:
             j_last = min(j_last, self.j_last_main)
-            self._sweep(max(j_first, 1), j_last, self.a[self.cur], self.b[self.cur],
+            self._sweep(max(j_first, self.G), j_last, self.a[self.cur], self.b[self.cur],
                         self.a[self.cur_hs], self.b[self.cur_hs], self.a[self.nxt], self.b[self.nxt], c0, c1)
         else:
             j_last = min(j_last, self.j_last_half)
-            self._sweep(max(j_first, 1), j_last, self.a[self.cur_hs], self.b[self.cur_hs],
+            self._sweep(max(j_first, self.G), j_last, self.a[self.cur_hs], self.b[self.cur_hs],
                         self.a[self.nxt], self.b[self.nxt], self.a[self.nxt_hs], self.b[self.nxt_hs], c0, c1)
 
     def _idx(self, which):
         return (self.cur_hs, self.nxt, self.nxt_hs)[which]
 
-    def pack(self, which, side, buf):
-        i, col = self._idx(which), (1 if side == 0 else self.W)
-        buf.copy_(self.torch.from_numpy(np.concatenate([self.a[i][:, col], self.b[i][:, col]])))
+    def step_fused_range(self, j2_first, j2_last, c):
+        """Same contract as slb_solver_step_fused_range, done as two oracle sweeps."""
+        G = self.G
+        j1_lo, j1_hi = (G if self.rank == 0 else G - 1), G + self.W
+        j2_first, j2_last = max(j2_first, G), min(j2_last, self.j_last_half)
+        if j2_last < j2_first:
+            return
+        self._sweep(max(j2_first - 1, j1_lo), min(j2_last + 1, j1_hi), self.a[self.cur], self.b[self.cur],
+                    self.a[self.cur_hs], self.b[self.cur_hs], self.a[self.nxt], self.b[self.nxt], c[0], c[1])
+        self._sweep(j2_first, j2_last, self.a[self.cur_hs], self.b[self.cur_hs],
+                    self.a[self.nxt], self.b[self.nxt], self.a[self.nxt_hs], self.b[self.nxt_hs], c[2], c[3])
 
-    def unpack(self, which, side, buf):
-        i, col = self._idx(which), (0 if side == 0 else self.W + 1)
-        v = buf.numpy()
-        self.a[i][:, col] = v[:self.N + 1]
-        self.b[i][:, col] = v[self.N + 1:]
+    def pack(self, which, side, ncols, buf):
+        i = self._idx(which)
+        col = self.G if side == 0 else self.G + self.W - ncols
+        parts = [arr[i][:, col + c] for arr in (self.a, self.b) for c in range(ncols)]
+        buf.copy_(self.torch.from_numpy(np.concatenate(parts)))
+
+    def unpack(self, which, side, ncols, buf):
+        i = self._idx(which)
+        col = self.G - ncols if side == 0 else self.G + self.W
+        v = buf.numpy().reshape(2, ncols, self.N + 1)
+        for q, arr in enumerate((self.a, self.b)):
+            for c in range(ncols):
+                arr[i][:, col + c] = v[q, c]
 
     def swap(self):
         self.cur, self.nxt = self.nxt, self.cur
@@ -98,8 +122,9 @@ class OracleEngine:
     def owned(self, which, idx):
         """owned columns (global 1..M, plus M+1.. on the last slab) of array idx"""
         arr = (self.a if which == "a" else self.b)[idx]
-        hi = self.pitch if self.rank == self.world - 1 else self.W + 1
-        lo = 0 if self.rank == 0 else 1
+        G = self.G
+        lo = G - 1 if self.rank == 0 else G                     # rank 0 adds boundary column 0
+        hi = G + self.W + 2 if self.rank == self.world - 1 else G + self.W   # last adds M+1, M+2
         return arr[:, lo:hi].copy()
 
 

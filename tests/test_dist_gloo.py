@@ -19,15 +19,18 @@ PHYS = dict(N=6, M=101, B=0.6, omega=40.0, E_omega=0.3)
 STEPS = 7
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, mode):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     slb, drv = sh.import_pkg()
     p = ob.make_params(**PHYS)
     eng = sh.OracleEngine(ob, p, rank, world)
     run = drv.SlabRun(slb, rank, world, engine=eng)
     run.tiptoe()
-    for _ in range(STEPS):
-        run.step()
+    for k in range(STEPS):
+        if mode == "fused" or (mode == "mixed" and k % 2 == 1):
+            run.step_fused()
+        else:
+            run.step()
     np.savez(os.path.join(outdir, f"r{rank}.npz"), t=eng.t,
              idx=np.array([eng.cur, eng.nxt, eng.cur_hs, eng.nxt_hs]),
              **{f"{w}{i}": eng.owned(w, i) for w in "ab" for i in range(4)})
@@ -35,9 +38,9 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slab_driver_matches_single_domain(world, tmp_path):
-    mp.spawn(_worker, args=(world, sh.free_port(), str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,mode", [(2, "sweeps"), (3, "sweeps"), (2, "fused"), (3, "fused"), (3, "mixed")])
+def test_slab_driver_matches_single_domain(world, mode, tmp_path):
+    mp.spawn(_worker, args=(world, sh.free_port(), str(tmp_path), mode), nprocs=world, join=True)
     p = ob.make_params(**PHYS)
     ref = ob.OracleState(p, threads=1)
     ref.step(STEPS)
@@ -60,7 +63,7 @@ def test_slab_columns_cover_the_grid():
                 continue
             nxt = 1
             for r in range(world):
-                W, off = sh.slab_columns(M, r, world)
-                assert off == nxt - 1 and W >= 1
+                W, first = sh.slab_columns(M, r, world)
+                assert first == nxt and W >= 1
                 nxt += W
             assert nxt == M + 1

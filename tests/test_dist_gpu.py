@@ -19,7 +19,7 @@ PHYS = dict(N=24, M=5003, B=0.8, omega=40.0, E_omega=0.3)
 STEPS = 9
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, mode):
     import torch
     torch.cuda.set_device(0)
     torch.zeros(1, device="cuda")
@@ -30,13 +30,16 @@ def _worker(rank, world, port, outdir):
                   B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
     run = drv.SlabRun(slb, rank, world)
     run.tiptoe()
-    for _ in range(STEPS):
-        run.step()
+    for k in range(STEPS):
+        if mode == "fused" or (mode == "mixed" and k % 2 == 1):
+            run.step_fused()
+        else:
+            run.step()
     torch.cuda.synchronize()
     sol = run.eng.sol
     s = sol.s
-    lo = 0 if rank == 0 else 1
-    hi = s.W + 3 if rank == world - 1 else s.W + 1
+    lo = s.G - 1 if rank == 0 else s.G
+    hi = s.G + s.W + 2 if rank == world - 1 else s.G + s.W
     np.savez(os.path.join(outdir, f"r{rank}.npz"), t=np.float32(s.t),
              idx=np.array([s.current, s.next, s.current_hs, s.next_hs]),
              **{f"a{i}": sol.rows(1 + i)[:, lo:hi] for i in range(4)},
@@ -46,9 +49,9 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_two_slabs_on_one_gpu(tmp_path):
-    world = 2
-    mp.spawn(_worker, args=(world, sh.free_port(), str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,mode", [(2, "sweeps"), (2, "fused"), (3, "mixed")])
+def test_slabs_on_one_gpu(world, mode, tmp_path):
+    mp.spawn(_worker, args=(world, sh.free_port(), str(tmp_path), mode), nprocs=world, join=True)
     p = ob.make_params(**PHYS)
     ref = ob.OracleState(p, threads=4)
     ref.step(STEPS)

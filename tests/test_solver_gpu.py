@@ -103,7 +103,7 @@ def test_fused_step_bit_exact(slb, oracle, N, M, B, omega, steps, n_chunk):
     L = slb.lib()
     try:
         sol.tiptoe()
-        for variant in (0, 6):
+        for variant in (0, 7, 9, 10, 12):
             L.slb_set_tuning(variant, n_chunk, 0)
             for _ in range(steps):
                 sol.step_fused()
