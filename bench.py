@@ -62,7 +62,7 @@ def main():
                     help="fused: both sweeps of a step in one launch (default); "
                          "sweeps: the reference's two launches per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=20)
     args = ap.parse_args()
 
     import torch
@@ -151,7 +151,7 @@ def main():
             if args.form == "fused":
                 kernel, alg_bytes = "fused_step_kernel", BYTES_PER_UPDATE_FUSED * points
             else:
-                kernel, alg_bytes = "sweep_kernel", BYTES_PER_POINT_SWEEP * points
+                kernel, alg_bytes = "sweep_pipe_kernel", BYTES_PER_POINT_SWEEP * points
             achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")

@@ -836,7 +836,7 @@ int slb_sweep(const slb_slab *slab,
                        aligned16(b_centre) && aligned16(a_stencil) && aligned16(b_stencil) &&
                        aligned16(a_out) && aligned16(b_out);
   int variant = g_variant;
-  if (variant == 0) variant = can_vec ? 2 : 1;
+  if (variant == 0) variant = can_vec ? 5 : 1;
   if (variant != 1 && !can_vec) {
     fprintf(stderr, "slb_sweep: variant %d needs a row pitch that is a multiple of 4 floats and 16-byte aligned arrays\n", variant);
     return -1;
@@ -844,18 +844,12 @@ int slb_sweep(const slb_slab *slab,
   const int block = g_block > 0 ? g_block : 256;
   if (block % 64 != 0 || block > 256) { fprintf(stderr, "slb_sweep: block must be 64, 128, 192 or 256\n"); return -1; }
 
-  // rows per workgroup: whole N when the columns alone fill the chip, else split
-  // n so that about 16 waves per CU exist; each split re-reads two stencil rows
+  // rows per workgroup: each chunk re-reads two stencil rows, but chunks of 16 rows measured
+  // fastest on MI355X at every large shape tried (waves of different chunks run out of phase),
+  // and narrow lattices need the extra workgroups to fill 256 CUs
   int n_chunk = g_n_chunk;
-  if (n_chunk <= 0) {
-    const int  V      = variant == 1 ? 1 : 4;
-    const long waves  = ((long)(slab->j_last - slab->j_first + 1) / V + 63) / 64 + 1;
-    const long target = 256L * 16L;
-    long split = waves >= target ? 1 : (target + waves - 1) / waves;
-    n_chunk = (int)((s.N + split - 1) / split);
-    if (n_chunk < 8) n_chunk = 8;
-    if (n_chunk > s.N) n_chunk = s.N;
-  }
+  if (n_chunk <= 0) n_chunk = 16;
+  if (n_chunk > s.N) n_chunk = s.N;
   s.n_chunk = n_chunk;
 
   switch (variant) {
@@ -901,16 +895,13 @@ int slb_step_fused(const slb_step_geom *g,
 
   const int block = g_block > 0 ? g_block : 256;
   if (block % 64 != 0 || block > 256) { fprintf(stderr, "slb_step_fused: block must be 64, 128, 192 or 256\n"); return -1; }
+  // Rows per workgroup.  Each chunk re-forms one main-sweep row above and below itself,
+  // so short chunks cost reads; but on MI355X chunks of 16 rows measured fastest at every
+  // large shape tried (waves of different chunks run out of phase and keep HBM busy), and
+  // narrow lattices need the extra workgroups anyway.
   int n_chunk = g_n_chunk;
-  if (n_chunk <= 0) {
-    const int  hi = s.j1_last > s.j2_last ? s.j1_last : s.j2_last;
-    const long waves  = (long)hi / (62 * 4) + 1;
-    const long target = 256L * 12L * 4L;               // several rounds of resident waves
-    long split = waves >= target ? 1 : (target + waves - 1) / waves;
-    n_chunk = (int)((s.N + split - 1) / split);
-    if (n_chunk < 16) n_chunk = 16;
-    if (n_chunk > s.N) n_chunk = s.N;
-  }
+  if (n_chunk <= 0) n_chunk = 16;
+  if (n_chunk > s.N) n_chunk = s.N;
   s.n_chunk = n_chunk;
   switch (g_variant) {
     case 6:  return launch_fused<false, false, 4>(s, block);
