@@ -131,6 +131,10 @@ int slb_main(int argc, char **argv)
   float *b_rows = (float *)malloc(sizeof(float) * 3 * (size_t)pitch);
   float av6[6] = {0, 0, 0, 0, 0, 0};
 
+  /* SLB_FORM=sweeps selects the reference's two launches per step */
+  const char *form = getenv("SLB_FORM");
+  const int two_launches = form != NULL && strcmp(form, "sweeps") == 0;
+
   int   progress = 0;
   float frame_time = 0;
   float t0 = 0, t = 0;
@@ -139,8 +143,13 @@ int slb_main(int argc, char **argv)
     for (t = t0; t < t_max; t += host_dt) {
       float c[4];
       slb_step_cosines(t, c);
-      slb_solver_sweep_main(s, c[0], c[1]);
-      slb_solver_sweep_half(s, c[2], c[3]);
+      if (two_launches) {
+        slb_solver_sweep_main(s, c[0], c[1]);
+        slb_solver_sweep_half(s, c[2], c[3]);
+      } else {
+        /* both sweeps in one launch; same bits */
+        slb_solver_step_fused_range(s, s->half_slab.j_first, s->half_slab.j_last, c);
+      }
 
       if (host_E_omega > 0 && display == 77 && frame_time >= 0.01) {
         av(0, s->a[s->next], s->b[s->next], s->av_data, t);

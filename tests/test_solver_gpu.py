@@ -118,3 +118,23 @@ def test_fused_step_bit_exact(slb, oracle, N, M, B, omega, steps, n_chunk):
         L.slb_set_tuning(0, 0, 0)
         sol.close()
         orc.close()
+
+
+def test_program_config1_matches_recorded_reference_line(solver_bin, tmp_path):
+    """BASELINE config 1 end to end on the GPU (16 281 steps, av every step of the
+    last period): the display=4 line equals, digit for digit, the line the
+    compiled reference CPU solver printed when it was surveyed."""
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                       "config1_display4_reference.json")))
+    for form in ("fused", "sweeps"):
+        r = subprocess.run([solver_bin] + gold["args"].split() + ["o=out.txt"], cwd=tmp_path,
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, SLB_FORM=form))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"# t_max = {gold['t_max']}" in r.stdout
+        lines = (tmp_path / "out.txt").read_text().splitlines()
+        assert len(lines) == 3
+        v = lines[2].split()
+        got = dict(zip(["v_dr/v_p", "A(omega)", "NORM", "v_y/v_p", "m/m_x", "<v_dr/v_p>", "<v_y/v_p>",
+                        "<m/m_x>", "Asin"], v[4:]))
+        assert got == gold["columns"], form
