@@ -121,6 +121,35 @@ int slb_step_fused(const slb_step_geom *geom,
                    float *a_next, float *b_next, float *a_next_hs, float *b_next_hs,
                    const float cosines[4]);
 
+/* Geometry of a double step: the columns each of the four sweeps produces
+ * (0 = main sweep at t, 1 = half-step sweep at t, 2 = main sweep at t+dt,
+ * 3 = half-step sweep at t+dt).  A single-GPU double step is
+ * {PADDED_MSIZE, 0, {1,1,1,1}, {M+1,M,M+1,M}}. */
+typedef struct slb_step2_geom {
+  int pitch, m_offset;
+  int j_first[4], j_last[4];
+} slb_step2_geom;
+
+/* TWO loop iterations in one launch (reference: two passes of the loop body
+ * src/boltzmann_solver.c:204-217 + :252-253).  The lattices at t+dt and
+ * t+3dt/2 are handed from sweep to sweep inside the kernel and never stored;
+ * a_out/b_out receive the main lattice at t+2dt, a_out_hs/b_out_hs the
+ * half-step lattice at t+5dt/2, bit-identical to four separate sweeps.
+ * a_next/b_next and a_next_hs/b_next_hs are only READ, at the cells no sweep
+ * writes (row N, boundary columns), where the reference's second iteration
+ * would find them.  The out arrays must not alias the inputs, and their
+ * never-written cells must already equal those of a_current/b_current
+ * (resp. the *_current_hs arrays): the caller keeps such spare arrays and
+ * exchanges them with the current ones after the call.  cosines[0..3] are the
+ * first iteration's, [4..7] the second's.  Returns like slb_sweep. */
+int slb_step_fused2(const slb_step2_geom *geom, const float *a0,
+                    const float *a_current, const float *b_current,
+                    const float *a_current_hs, const float *b_current_hs,
+                    const float *a_next, const float *b_next,
+                    const float *a_next_hs, const float *b_next_hs,
+                    float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
+                    const float cosines[8]);
+
 /* Gather local columns col..col+ncols-1 of rows 0..nrows-1 of arrays a and b
  * into buf (a's columns first, each column contiguous: buf[(q*ncols + c)*nrows + r],
  * q = 0 for a, 1 for b); and the inverse scatter.  buf holds 2*ncols*nrows floats. */

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--chunks", default="0,8,16,32,64,128")
     ap.add_argument("--blocks", default="256,128,64")
     ap.add_argument("--fused", action="store_true", help="time the one-launch step (variants 6, 7)")
+    ap.add_argument("--double", action="store_true", help="time the double step (variants 21-25)")
     args = ap.parse_args()
     import torch
     slb = importlib.import_module("super-lattice-boltzmann-2d_amd")
@@ -29,9 +30,11 @@ def main():
     L = slb.lib()
     sol = slb.Solver()
     sol.tiptoe()
-    sol.set_fused(args.fused)
-    per_launch = 1 if args.fused else 2
-    bytes_per_point = 36.0 if args.fused else 28.0
+    sol.set_fused(2 if args.double else args.fused)
+    per_launch = 0.5 if args.double else (1 if args.fused else 2)
+    bytes_per_point = 36.0 if (args.fused or args.double) else 28.0
+    if args.double:
+        sol.double_step()
     for v in [int(x) for x in args.variants.split(",")]:
         for nc in [int(x) for x in args.chunks.split(",")]:
             for b in [int(x) for x in args.blocks.split(",")]:

@@ -23,7 +23,7 @@ _INT_GLOBALS = ("host_M", "host_N", "MSIZE", "MP1", "NSIZE", "host_TMSIZE", "PAD
 
 # every symbol include/slb_abi.h declares
 ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "HandleError",
-                 "slb_sweep", "slb_step_fused", "slb_halo_pack", "slb_halo_unpack", "slb_av_partial",
+                 "slb_sweep", "slb_step_fused", "slb_step_fused2", "slb_halo_pack", "slb_halo_unpack", "slb_av_partial",
                  "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream",
                  "slb_set_tuning", "slb_version")
 ABI_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha",
@@ -52,7 +52,9 @@ class SolverStruct(C.Structure):
                 ("av_data", C.c_void_p), ("sums", C.c_void_p), ("halo_buf", C.c_void_p),
                 ("current", C.c_int), ("next", C.c_int), ("current_hs", C.c_int), ("next_hs", C.c_int),
                 ("t", C.c_float), ("frame_time", C.c_float), ("steps", C.c_long), ("fused", C.c_int),
-                ("G", C.c_int)]
+                ("G", C.c_int),
+                ("spare_a", C.c_void_p), ("spare_b", C.c_void_p), ("spare_ah", C.c_void_p),
+                ("spare_bh", C.c_void_p), ("spare_of", C.c_int), ("spare_of_hs", C.c_int)]
 
 
 _lib = None
@@ -108,6 +110,7 @@ def lib():
         L.slb_step_cosines.argtypes, L.slb_step_cosines.restype = [f, C.POINTER(C.c_float * 4)], None
         L.slb_solver_step.argtypes, L.slb_solver_step.restype = [C.POINTER(SolverStruct)], None
         L.slb_solver_step_fused.argtypes, L.slb_solver_step_fused.restype = [C.POINTER(SolverStruct)], None
+        L.slb_solver_double_step.argtypes, L.slb_solver_double_step.restype = [C.POINTER(SolverStruct)], None
         L.slb_solver_step_fused_range.argtypes = [C.POINTER(SolverStruct), i, i, C.POINTER(C.c_float * 4)]
         L.slb_solver_step_fused_range.restype = None
         L.slb_solver_run_timed.argtypes = [C.POINTER(SolverStruct), i, C.POINTER(C.c_float)]
@@ -182,8 +185,12 @@ class Solver:
     def step_fused(self):
         lib().slb_solver_step_fused(self._p)
 
+    def double_step(self):
+        lib().slb_solver_double_step(self._p)
+
     def set_fused(self, on):
-        self._p.contents.fused = 1 if on else 0
+        """0/False: two launches per step; 1/True: one launch per step; 2: one launch per two steps."""
+        self._p.contents.fused = int(on)
 
     def sweep_main(self, c0, c1):
         lib().slb_solver_sweep_main(self._p, c0, c1)

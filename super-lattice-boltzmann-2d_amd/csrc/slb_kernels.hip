@@ -588,6 +588,234 @@ fused_step_kernel(const FusedArgs p)
 }
 
 // ---------------------------------------------------------------------------
+// double step: TWO loop iterations (four sweeps) in one pass over the lattice.
+//
+// Stage A = main sweep at t, B = half-step sweep at t, C = main sweep at t+dt,
+// D = half-step sweep at t+dt.  Each stage reads the previous stage's output at
+// rows n+-1, columns m+-1 (reference: src/boltzmann_c_solver.c:370-372, 400-402),
+// so a lane walking n upward runs A at row r, B at r-1, C at r-2, D at r-3 and
+// hands rows from stage to stage in registers; columns m+-1 come from the
+// adjacent lanes.  Three stage hand-offs cost three columns of validity per side,
+// which the one halo lane (four columns) on each side of a wave still covers.
+// Only C's and D's outputs (the lattices at t+2dt and t+5dt/2) are stored; the
+// lattices in between never reach memory: 5 reads + 4 writes = 36 B per TWO
+// lattice-point updates.
+//
+// Cells no sweep writes (row N, boundary columns) differ from buffer to buffer in
+// the reference's ping-pong; each stage takes them from the buffer that would
+// hold its output there: stage A from p1a/p1b (the reference's a/b[next]), stage B
+// from p2a/p2b (a/b[next_hs]), stage C from its own output arrays.  The outputs
+// must not alias the inputs (halo lanes of other waves still read them), so the
+// caller passes spare arrays whose never-written cells equal those of a/b[current]
+// and a/b[current_hs], and exchanges them with those afterwards.
+// ---------------------------------------------------------------------------
+struct Fused2Args {
+  const float *a0, *a_c, *b_c, *a_h, *b_h;   // a0; main lattice (t); half-step lattice (t+dt/2)
+  const float *p1a, *p1b, *p2a, *p2b;        // never-written cells of the in-between lattices
+  float *a_o, *b_o, *a_ho, *b_ho;            // main lattice (t+2dt); half-step lattice (t+5dt/2)
+  float E_dc, E_omega, B, dt, dPhi, PhiYmin, nu, nu2, nu_tilde, bdt;
+  float c[8];                                // cosines: stage A 0,1  B 2,3  C 4,5  D 6,7
+  int N, pitch, m_offset, n_chunk, jj0;
+  int jf[4], jl[4];                          // columns stage A, B, C, D produce
+};
+
+template <bool PF, int MINW, bool DIAG = false>
+__global__ void __launch_bounds__(256, MINW)
+fused2_step_kernel(const Fused2Args p)
+{
+  constexpr int V = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int jj   = p.jj0 + (wave * 62 + lane - 1) * V;          // first own column (may be < 0)
+  int j_hi = p.jl[0];
+#pragma unroll
+  for (int q = 1; q < 4; q++) j_hi = p.jl[q] > j_hi ? p.jl[q] : j_hi;
+  if (p.jj0 + wave * 62 * V > j_hi) return;                     // whole wave past the end
+  const bool interior = lane >= 1 && lane <= 62;
+  const int jcl = jj < 0 ? 0 : (jj > p.pitch - V ? p.pitch - V : jj);
+  const unsigned j = (unsigned)jcl;
+
+  const int n0 = blockIdx.y * p.n_chunk;
+  const int n1 = n0 + p.n_chunk < p.N ? n0 + p.n_chunk : p.N;
+  // first row each stage has to form so that D can form rows n0..n1-1
+  const int c_lo = n0 > 1 ? n0 - 1 : 0, b_lo = n0 > 2 ? n0 - 2 : 0, a_lo = n0 > 3 ? n0 - 3 : 0;
+  const int r_end = n1 + 2;                      // D forms row n1-1 when A stands at n1+2
+
+  // per-column flags.  bits 0-3: stage A produces column k; 4-7: B; 8-11: C;
+  // 12-15: C stores column k; 16-19: D stores column k
+  float bphi[V];
+  unsigned flags = 0;
+  bool need1 = false, need2 = false, need3 = false;
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    const int c = jj + k;
+    bphi[k] = p.B * (p.PhiYmin + p.dPhi * (float)(p.m_offset + c - 1));
+    const bool in_row = c >= 0 && c < p.pitch;
+    const bool okA = c >= p.jf[0] && c <= p.jl[0], okB = c >= p.jf[1] && c <= p.jl[1];
+    const bool okC = c >= p.jf[2] && c <= p.jl[2], okD = c >= p.jf[3] && c <= p.jl[3];
+    if (okA) flags |= 1u << k;
+    if (okB) flags |= 1u << (4 + k);
+    if (okC) flags |= 1u << (8 + k);
+    if (okC && interior) flags |= 1u << (12 + k);
+    if (okD && interior) flags |= 1u << (16 + k);
+    // a column the next stage reads at m+-1 that this stage does not produce keeps its old value
+    if (!okA && in_row && c >= p.jf[1] - 1 && c <= p.jl[1] + 1) need1 = true;
+    if (!okB && in_row && c >= p.jf[2] - 1 && c <= p.jl[2] + 1) need2 = true;
+    if (!okC && in_row && c >= p.jf[3] - 1 && c <= p.jl[3] + 1) need3 = true;
+  }
+  if (jj != jcl) need1 = need2 = need3 = false;
+  const bool wC_all = ((flags >> 12) & 0xfu) == 0xfu, wD_all = ((flags >> 16) & 0xfu) == 0xfu;
+  float s[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) s[q] = p.E_dc + p.E_omega * p.c[q];
+
+  const size_t P = (size_t)p.pitch;
+
+  auto load4 = [&](const float *base, size_t row, float (&v)[V]) {
+    const float4 q = *reinterpret_cast<const float4 *>(base + row + j);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  };
+  // replace the columns a stage does not produce by the present contents of `pa`/`pb`
+  auto keep_old = [&](const float *pa, const float *pb, size_t row, unsigned okbits,
+                      float (&oa)[V], float (&ob)[V]) {
+    float xa[V], xb[V];
+    load4(pa, row, xa); load4(pb, row, xb);
+#pragma unroll
+    for (int k = 0; k < V; k++)
+      if (!(okbits & (1u << k))) { oa[k] = xa[k]; ob[k] = xb[k]; }
+  };
+  // one stage at row n for the four own columns
+  auto stage = [&](int n, float sa, float sb, const float (&a0v)[V], const float (&ca)[V], const float (&cb)[V],
+                   const float (&upa)[6], const float (&upb)[6], const float (&dla)[V], const float (&dlb)[V],
+                   float (&oa)[V], float (&ob)[V]) {
+    const float fn = (float)n;
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      const float mu_a = (sa + bphi[k]) * p.dt / 2.0f, mu_b = (sb + bphi[k]) * p.dt / 2.0f;
+      point_update_sel<DIAG>(p, n, fn, mu_a, mu_b, a0v[k], ca[k], cb[k],
+                             upa[k + 2], upa[k], upb[k + 2], upb[k], dla[k], dlb[k], oa[k], ob[k]);
+    }
+  };
+  auto diffs = [&](const float (&own)[V], float (&d)[V]) {
+    float e[6];
+    widen(own, e);
+#pragma unroll
+    for (int k = 0; k < V; k++) d[k] = e[k + 2] - e[k];
+  };
+
+  // sliding state, named by the row they hold relative to stage A's row r
+  float hA_p[V] = {}, hB_p[V] = {}, hA_c[V], hB_c[V];           // half-step lattice rows r-1, r
+  float a0_1[V] = {}, a0_2[V] = {}, a0_3[V] = {};               // a0 rows r-1, r-2, r-3
+  float o1A_p[V] = {}, o1B_p[V] = {}, o1A_pp[V] = {}, o1B_pp[V] = {};   // stage A output rows r-1, r-2
+  float o2A_p[V] = {}, o2B_p[V] = {}, o2A_pp[V] = {}, o2B_pp[V] = {};   // stage B output rows r-2, r-3
+  float d3A_p[V] = {}, d3B_p[V] = {}, d3A_pp[V] = {}, d3B_pp[V] = {};   // stage C output rows r-3, r-4: X[m+1]-X[m-1]
+
+  if (a_lo >= 1) { load4(p.a_h, (size_t)(a_lo - 1) * P, hA_p); load4(p.b_h, (size_t)(a_lo - 1) * P, hB_p); }
+  load4(p.a_h, (size_t)a_lo * P, hA_c); load4(p.b_h, (size_t)a_lo * P, hB_c);
+
+  struct RowIn { float a0[V], ac[V], bc[V], hA[V], hB[V]; };
+  auto load_row = [&](int r, RowIn &in) {
+    const size_t row = (size_t)r * P;
+    load4(p.a0, row, in.a0); load4(p.a_c, row, in.ac); load4(p.b_c, row, in.bc);
+    load4(p.a_h, row + P, in.hA); load4(p.b_h, row + P, in.hB);
+  };
+  RowIn cur = {}, nxt = {};
+  if constexpr (PF) { if (a_lo < p.N) load_row(a_lo, cur); }
+
+  for (int r = a_lo; r <= r_end; r++) {
+    if constexpr (PF) { if (r + 1 <= r_end && r + 1 < p.N) load_row(r + 1, nxt); }
+
+    // ---- stage A: main sweep at t, row r ----
+    float o1A[V] = {}, o1B[V] = {};
+    if (r < p.N) {
+      if constexpr (!PF) load_row(r, cur);
+      float ea[6], eb[6], dla[V], dlb[V];
+      widen(cur.hA, ea); widen(cur.hB, eb);
+      diffs(hA_p, dla);  diffs(hB_p, dlb);
+      stage(r, s[0], s[1], cur.a0, cur.ac, cur.bc, ea, eb, dla, dlb, o1A, o1B);
+      if (need1) keep_old(p.p1a, p.p1b, (size_t)r * P, flags, o1A, o1B);
+    } else if (r == p.N) {
+      load4(p.p1a, (size_t)r * P, o1A); load4(p.p1b, (size_t)r * P, o1B);
+    }
+
+    // ---- stage B: half-step sweep at t, row r-1 ----
+    const int rb = r - 1;
+    float o2A[V] = {}, o2B[V] = {};
+    if (rb >= b_lo && rb < p.N) {
+      float ea[6], eb[6], dla[V], dlb[V];
+      widen(o1A, ea); widen(o1B, eb);
+      diffs(o1A_pp, dla); diffs(o1B_pp, dlb);
+      stage(rb, s[2], s[3], a0_1, hA_p, hB_p, ea, eb, dla, dlb, o2A, o2B);
+      if (need2) keep_old(p.p2a, p.p2b, (size_t)rb * P, flags >> 4, o2A, o2B);
+    } else if (rb == p.N) {
+      load4(p.p2a, (size_t)rb * P, o2A); load4(p.p2b, (size_t)rb * P, o2B);
+    }
+
+    // ---- stage C: main sweep at t+dt, row r-2 (stored) ----
+    const int rc = r - 2;
+    float o3A[V] = {}, o3B[V] = {};
+    if (rc >= c_lo && rc < p.N) {
+      float ea[6], eb[6], dla[V], dlb[V];
+      widen(o2A, ea); widen(o2B, eb);
+      diffs(o2A_pp, dla); diffs(o2B_pp, dlb);
+      stage(rc, s[4], s[5], a0_2, o1A_pp, o1B_pp, ea, eb, dla, dlb, o3A, o3B);
+      const size_t row = (size_t)rc * P;
+      if (rc >= n0 && rc < n1) {
+        if (wC_all) {
+          st4<false>(p.a_o + row, j, o3A);
+          if (rc > 0) st4<false>(p.b_o + row, j, o3B);
+        } else {
+#pragma unroll
+          for (int k = 0; k < V; k++) {
+            if (flags & (1u << (12 + k))) {
+              p.a_o[row + j + k] = o3A[k];
+              if (rc > 0) p.b_o[row + j + k] = o3B[k];
+            }
+          }
+        }
+      }
+      if (need3) keep_old(p.a_o, p.b_o, row, flags >> 8, o3A, o3B);
+    } else if (rc == p.N) {
+      load4(p.a_o, (size_t)rc * P, o3A); load4(p.b_o, (size_t)rc * P, o3B);
+    }
+
+    // ---- stage D: half-step sweep at t+dt, row r-3 (stored) ----
+    const int rd = r - 3;
+    float e3a[6], e3b[6];
+    widen(o3A, e3a); widen(o3B, e3b);
+    if (rd >= n0 && rd < n1) {
+      float o4A[V], o4B[V];
+      stage(rd, s[6], s[7], a0_3, o2A_pp, o2B_pp, e3a, e3b, d3A_pp, d3B_pp, o4A, o4B);
+      const size_t row = (size_t)rd * P;
+      if (wD_all) {
+        st4<false>(p.a_ho + row, j, o4A);
+        if (rd > 0) st4<false>(p.b_ho + row, j, o4B);
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+          if (flags & (1u << (16 + k))) {
+            p.a_ho[row + j + k] = o4A[k];
+            if (rd > 0) p.b_ho[row + j + k] = o4B[k];
+          }
+        }
+      }
+    }
+
+    // ---- slide every window one row up ----
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      d3A_pp[k] = d3A_p[k]; d3B_pp[k] = d3B_p[k];
+      d3A_p[k] = e3a[k + 2] - e3a[k]; d3B_p[k] = e3b[k + 2] - e3b[k];
+      o2A_pp[k] = o2A_p[k]; o2B_pp[k] = o2B_p[k]; o2A_p[k] = o2A[k]; o2B_p[k] = o2B[k];
+      o1A_pp[k] = o1A_p[k]; o1B_pp[k] = o1B_p[k]; o1A_p[k] = o1A[k]; o1B_p[k] = o1B[k];
+      a0_3[k] = a0_2[k]; a0_2[k] = a0_1[k]; a0_1[k] = cur.a0[k];
+      hA_p[k] = hA_c[k]; hB_p[k] = hB_c[k]; hA_c[k] = cur.hA[k]; hB_c[k] = cur.hB[k];
+    }
+    if constexpr (PF) cur = nxt;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // halo movers: one column of rows 0..nrows-1 of two arrays <-> contiguous buffer
 // ---------------------------------------------------------------------------
 // buf[(q*ncols + c)*nrows + r] <-> array q (0 = a, 1 = b), row r, column col + c
@@ -775,6 +1003,20 @@ int launch_fused(FusedArgs &args, int block)
   return (int)hipGetLastError();
 }
 
+template <bool PF, int MINW, bool DIAG = false>
+int launch_fused2(Fused2Args &args, int block)
+{
+  int lo = args.jf[0], hi = args.jl[0];
+  for (int q = 1; q < 4; q++) { lo = args.jf[q] < lo ? args.jf[q] : lo; hi = args.jl[q] > hi ? args.jl[q] : hi; }
+  args.jj0 = lo / 4 * 4;
+  const int per_wave = 62 * 4;
+  const int waves = (hi + 1 - args.jj0 + per_wave - 1) / per_wave;
+  const int wpb = block / 64;
+  dim3 grid((waves + wpb - 1) / wpb, (args.N + args.n_chunk - 1) / args.n_chunk);
+  hipLaunchKernelGGL((fused2_step_kernel<PF, MINW, DIAG>), grid, dim3(block), 0, g_stream, args);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -913,6 +1155,60 @@ int slb_step_fused(const slb_step_geom *g,
     case 12: return launch_fused<false, false, 6>(s, block);
     case 99: return launch_fused<false, false, 4, true>(s, block);   // timing only, wrong results
     default: return launch_fused<false, false, 4>(s, block);
+  }
+}
+
+int slb_step_fused2(const slb_step2_geom *g, const float *a0,
+                    const float *a_current, const float *b_current,
+                    const float *a_current_hs, const float *b_current_hs,
+                    const float *a_next, const float *b_next,
+                    const float *a_next_hs, const float *b_next_hs,
+                    float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
+                    const float cosines[8])
+{
+  if (!g_phys.loaded) { fprintf(stderr, "slb_step_fused2: load_data() has not been called\n"); return -1; }
+  if (!g || g->pitch < 4 || g->pitch % 4 != 0 || g_phys.N < 1) { fprintf(stderr, "slb_step_fused2: bad geometry\n"); return -1; }
+  for (int q = 0; q < 4; q++) {
+    if (g->j_first[q] < 1 || g->j_last[q] > g->pitch - 2) { fprintf(stderr, "slb_step_fused2: bad column range\n"); return -1; }
+    // every stage must be able to take its m+-1 neighbours from the stage before it or from
+    // never-written cells: ranges may only shrink by at most... they are the caller's contract
+  }
+  const void *ptrs[13] = {a0, a_current, b_current, a_current_hs, b_current_hs, a_next, b_next,
+                          a_next_hs, b_next_hs, a_out, b_out, a_out_hs, b_out_hs};
+  for (int i = 0; i < 13; i++)
+    if (!aligned16(ptrs[i])) { fprintf(stderr, "slb_step_fused2: arrays must be 16-byte aligned\n"); return -1; }
+  if (a_out == a_current || b_out == b_current || a_out_hs == a_current_hs || b_out_hs == b_current_hs) {
+    fprintf(stderr, "slb_step_fused2: outputs must not alias the inputs\n");
+    return -1;
+  }
+  if (g->j_last[3] < g->j_first[3] && g->j_last[2] < g->j_first[2]) return 0;
+
+  Fused2Args s;
+  s.a0 = a0; s.a_c = a_current; s.b_c = b_current; s.a_h = a_current_hs; s.b_h = b_current_hs;
+  s.p1a = a_next; s.p1b = b_next; s.p2a = a_next_hs; s.p2b = b_next_hs;
+  s.a_o = a_out; s.b_o = b_out; s.a_ho = a_out_hs; s.b_ho = b_out_hs;
+  s.E_dc = g_phys.E_dc; s.E_omega = g_phys.E_omega; s.B = g_phys.B; s.dt = g_phys.dt;
+  s.dPhi = g_phys.dPhi; s.PhiYmin = g_phys.PhiYmin; s.nu = g_phys.nu; s.nu2 = g_phys.nu2;
+  s.nu_tilde = g_phys.nu_tilde; s.bdt = g_phys.bdt;
+  for (int q = 0; q < 8; q++) s.c[q] = cosines[q];
+  s.N = g_phys.N; s.pitch = g->pitch; s.m_offset = g->m_offset;
+  for (int q = 0; q < 4; q++) { s.jf[q] = g->j_first[q]; s.jl[q] = g->j_last[q]; }
+
+  const int block = g_block > 0 ? g_block : 256;
+  if (block % 64 != 0 || block > 256) { fprintf(stderr, "slb_step_fused2: block must be 64, 128, 192 or 256\n"); return -1; }
+  // each chunk re-forms three rows of stage A above and below itself (two of B, one of C)
+  int n_chunk = g_n_chunk;
+  if (n_chunk <= 0) n_chunk = 64;
+  if (n_chunk > s.N) n_chunk = s.N;
+  s.n_chunk = n_chunk;
+  switch (g_variant) {
+    case 21: return launch_fused2<false, 2>(s, block);
+    case 22: return launch_fused2<true, 2>(s, block);
+    case 23: return launch_fused2<false, 3>(s, block);
+    case 24: return launch_fused2<true, 3>(s, block);
+    case 25: return launch_fused2<false, 4>(s, block);
+    case 98: return launch_fused2<false, 3, true>(s, block);   // timing only, wrong results
+    default: return launch_fused2<false, 3>(s, block);
   }
 }
 

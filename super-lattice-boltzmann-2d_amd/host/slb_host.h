@@ -53,6 +53,10 @@ typedef struct slb_solver {
   long  steps;
   int   fused;           /* run_timed / the program use the one-launch step       */
   int   G;               /* ghost columns per side; owned columns are G..G+W-1    */
+  /* spare arrays for the double step (outputs must not alias inputs): their
+   * never-written cells mirror a/b[spare_of] and a/b[spare_of_hs] */
+  float *spare_a, *spare_b, *spare_ah, *spare_bh;
+  int   spare_of, spare_of_hs;
 } slb_solver;
 
 /* Allocate the slab of rank `rank` of `nranks`, build a0 for its columns
@@ -88,6 +92,11 @@ void slb_solver_step_fused(slb_solver *s);
 /* the fused step for half-step-lattice columns j2_first..j2_last only (no swap,
  * no time advance); c = slb_step_cosines() of the current time */
 void slb_solver_step_fused_range(slb_solver *s, int j2_first, int j2_last, const float c[4]);
+
+/* TWO loop iterations in one launch (slb_step_fused2); single slab.  The first
+ * call allocates four spare arrays.  Same state afterwards as two
+ * slb_solver_step() calls, bit for bit (ping-pong indices included). */
+void slb_solver_double_step(slb_solver *s);
 
 /* `steps` iterations bracketed by HIP events on the launch stream; *ms gets the
  * elapsed device time.  Single slab. */

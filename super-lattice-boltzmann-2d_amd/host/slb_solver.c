@@ -126,6 +126,7 @@ void slb_solver_destroy(slb_solver *s)
   hipFree(s->a0);
   for (int i = 0; i < 4; i++) { hipFree(s->a[i]); hipFree(s->b[i]); }
   hipFree(s->av_data); hipFree(s->sums); hipFree(s->halo_buf);
+  if (s->spare_a) { hipFree(s->spare_a); hipFree(s->spare_b); hipFree(s->spare_ah); hipFree(s->spare_bh); }
   free(s);
 }
 
@@ -247,6 +248,51 @@ void slb_solver_step_fused(slb_solver *s)
   slb_solver_advance(s);
 }
 
+/* (re)build the spare arrays as full copies of the current lattices, so that every
+ * cell the sweeps never write is what the reference would find in these buffers */
+static void sync_spares(slb_solver *s)
+{
+  const size_t bytes = (size_t)(s->N + 1) * (size_t)s->pitch * sizeof(float);
+  if (!s->spare_a) {
+    HIP_OK(hipMalloc((void **)&s->spare_a, bytes));
+    HIP_OK(hipMalloc((void **)&s->spare_b, bytes));
+    HIP_OK(hipMalloc((void **)&s->spare_ah, bytes));
+    HIP_OK(hipMalloc((void **)&s->spare_bh, bytes));
+  }
+  hipStream_t st = (hipStream_t)slb_get_stream();
+  HIP_OK(hipMemcpyAsync(s->spare_a,  s->a[s->current],    bytes, hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(s->spare_b,  s->b[s->current],    bytes, hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(s->spare_ah, s->a[s->current_hs], bytes, hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(s->spare_bh, s->b[s->current_hs], bytes, hipMemcpyDeviceToDevice, st));
+  s->spare_of = s->current; s->spare_of_hs = s->current_hs;
+}
+
+void slb_solver_double_step(slb_solver *s)
+{
+  if (!s->spare_a || s->spare_of != s->current || s->spare_of_hs != s->current_hs) sync_spares(s);
+  float c[8];
+  slb_step_cosines(s->t, c);
+  const float t2 = s->t + host_dt;              /* the loop variable after one iteration */
+  slb_step_cosines(t2, c + 4);
+  slb_step2_geom g;
+  g.pitch = s->pitch; g.m_offset = s->m_offset;
+  g.j_first[0] = g.j_first[2] = s->main_slab.j_first; g.j_last[0] = g.j_last[2] = s->main_slab.j_last;
+  g.j_first[1] = g.j_first[3] = s->half_slab.j_first; g.j_last[1] = g.j_last[3] = s->half_slab.j_last;
+  check_sweep(slb_step_fused2(&g, s->a0, s->a[s->current], s->b[s->current],
+                              s->a[s->current_hs], s->b[s->current_hs],
+                              s->a[s->next], s->b[s->next], s->a[s->next_hs], s->b[s->next_hs],
+                              s->spare_a, s->spare_b, s->spare_ah, s->spare_bh, c), __LINE__);
+  /* after two iterations the ping-pong indices are back where they were; the
+   * arrays that now hold those lattices are the former spares */
+  float *x;
+  x = s->a[s->current];    s->a[s->current]    = s->spare_a;  s->spare_a  = x;
+  x = s->b[s->current];    s->b[s->current]    = s->spare_b;  s->spare_b  = x;
+  x = s->a[s->current_hs]; s->a[s->current_hs] = s->spare_ah; s->spare_ah = x;
+  x = s->b[s->current_hs]; s->b[s->current_hs] = s->spare_bh; s->spare_bh = x;
+  slb_solver_advance(s);
+  slb_solver_advance(s);
+}
+
 int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
 {
   hipStream_t st = (hipStream_t)slb_get_stream();
@@ -254,7 +300,12 @@ int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
   HIP_OK(hipEventRecord(e0, st));
-  for (int i = 0; i < steps; i++) {
+  int i = 0;
+  if (s->fused == 2) {
+    /* warm the spares outside the timed region only when they are missing */
+    for (; i + 1 < steps; i += 2) slb_solver_double_step(s);
+  }
+  for (; i < steps; i++) {
     if (s->fused) slb_solver_step_fused(s); else slb_solver_step(s);
   }
   HIP_OK(hipEventRecord(e1, st));

@@ -138,3 +138,62 @@ def test_program_config1_matches_recorded_reference_line(solver_bin, tmp_path):
         got = dict(zip(["v_dr/v_p", "A(omega)", "NORM", "v_y/v_p", "m/m_x", "<v_dr/v_p>", "<v_y/v_p>",
                         "<m/m_x>", "Asin"], v[4:]))
         assert got == gold["columns"], form
+
+
+def _compare_live_state(sol, orc, M):
+    """After a double step the lattices at t+dt and t+3dt/2 were never stored, so
+    the `next` buffers hold older data than the oracle's; nothing ever reads that
+    data again (the next sweep overwrites it).  What must agree: a0, the current
+    lattices in full, and the cells of the `next` buffers that no sweep writes."""
+    s = sol.s
+    assert (s.current, s.next, s.current_hs, s.next_hs) == \
+           (orc.st.current, orc.st.next, orc.st.current_hs, orc.st.next_hs)
+    N = s.N
+    for which, i, arr in (("a0", 0, 0), ("a", s.current, 1 + s.current), ("b", s.current, 5 + s.current),
+                          ("a", s.current_hs, 1 + s.current_hs), ("b", s.current_hs, 5 + s.current_hs)):
+        got, exp = sol.rows(arr)[:, :M + 3], orc.array(which, i)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (which, i)
+    for which, i, arr, hs in (("a", s.next, 1 + s.next, False), ("b", s.next, 5 + s.next, False),
+                              ("a", s.next_hs, 1 + s.next_hs, True), ("b", s.next_hs, 5 + s.next_hs, True)):
+        got, exp = sol.rows(arr)[:, :M + 3].view(np.uint32), orc.array(which, i).view(np.uint32)
+        assert np.array_equal(got[N], exp[N]), (which, i, "row N")
+        assert np.array_equal(got[:, 0], exp[:, 0]) and np.array_equal(got[:, M + 2], exp[:, M + 2]), (which, i)
+        if hs:
+            assert np.array_equal(got[:, M + 1], exp[:, M + 1]), (which, i, "column M+1")
+        if which == "b":
+            assert np.array_equal(got[0], exp[0]), (which, i, "row 0")
+
+
+@pytest.mark.parametrize("N,M,B,omega,pairs,n_chunk", [
+    (1, 5, 0.5, 3.0, 2, 0), (2, 61, 0.05, 100.0, 3, 0), (3, 61, 0.05, 100.0, 3, 2), (4, 300, 0.4, 10.0, 3, 3),
+    (7, 300, 0.4, 10.0, 3, 4), (32, 4096, 1.0, 1.0, 10, 0), (33, 1000, 0.5, 30.0, 4, 5),
+    (64, 20001, 0.2, 10.0, 3, 16), (16, 247, 0.3, 10.0, 2, 0), (16, 248, 0.3, 10.0, 2, 8),
+    (16, 249, 0.3, 10.0, 2, 1), (128, 70000, 0.06, 50.0, 2, 32),
+])
+def test_double_step_bit_exact(slb, oracle, N, M, B, omega, pairs, n_chunk):
+    """Two loop iterations per launch: after every pair of steps all nine arrays,
+    the ping-pong indices and the loop time equal the oracle's, bit for bit."""
+    p = oracle.make_params(N=N, M=M, B=B, omega=omega)
+    slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    orc = oracle.OracleState(p)
+    sol = slb.Solver()
+    L = slb.lib()
+    try:
+        sol.tiptoe()
+        for variant in (0, 21, 22, 25):
+            L.slb_set_tuning(variant, n_chunk, 0)
+            for _ in range(pairs):
+                sol.double_step()
+            orc.step(2 * pairs)
+            _compare_live_state(sol, orc, M)
+            assert sol.s.t == orc.st.t
+        # an odd step in between changes which buffers are current: the spares follow
+        L.slb_set_tuning(0, 0, 0)
+        sol.step_fused(); sol.double_step(); sol.step(); sol.double_step()
+        orc.step(6)
+        _compare_live_state(sol, orc, M)
+    finally:
+        L.slb_set_tuning(0, 0, 0)
+        sol.close()
+        orc.close()
