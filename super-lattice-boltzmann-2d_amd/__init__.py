@@ -111,6 +111,11 @@ def lib():
         L.slb_solver_step.argtypes, L.slb_solver_step.restype = [C.POINTER(SolverStruct)], None
         L.slb_solver_step_fused.argtypes, L.slb_solver_step_fused.restype = [C.POINTER(SolverStruct)], None
         L.slb_solver_double_step.argtypes, L.slb_solver_double_step.restype = [C.POINTER(SolverStruct)], None
+        L.slb_solver_double_step_range.argtypes = [C.POINTER(SolverStruct), i, i, C.POINTER(C.c_float * 8)]
+        L.slb_solver_double_step_range.restype = None
+        L.slb_solver_double_step_finish.argtypes = [C.POINTER(SolverStruct)]
+        L.slb_solver_double_step_finish.restype = None
+        L.slb_step2_cosines.argtypes, L.slb_step2_cosines.restype = [f, C.POINTER(C.c_float * 8)], None
         L.slb_solver_step_fused_range.argtypes = [C.POINTER(SolverStruct), i, i, C.POINTER(C.c_float * 4)]
         L.slb_solver_step_fused_range.restype = None
         L.slb_solver_run_timed.argtypes = [C.POINTER(SolverStruct), i, C.POINTER(C.c_float)]
@@ -188,6 +193,13 @@ class Solver:
     def double_step(self):
         lib().slb_solver_double_step(self._p)
 
+    def double_step_range(self, j_first, j_last, cosines8):
+        c = (C.c_float * 8)(*cosines8)
+        lib().slb_solver_double_step_range(self._p, j_first, j_last, C.byref(c))
+
+    def double_step_finish(self):
+        lib().slb_solver_double_step_finish(self._p)
+
     def set_fused(self, on):
         """0/False: two launches per step; 1/True: one launch per step; 2: one launch per two steps."""
         self._p.contents.fused = int(on)
@@ -249,6 +261,12 @@ class Solver:
         if rc:
             raise RuntimeError(f"slb_solver_get_window -> {rc}")
         return out
+
+
+def step2_cosines(t):
+    c = (C.c_float * 8)()
+    lib().slb_step2_cosines(t, C.byref(c))
+    return tuple(c)
 
 
 def step_cosines(t):

@@ -6,9 +6,9 @@ The reference is single-GPU; this driver is additive.  Coupling along phi_y is
 +-1 column on the lattice a sweep reads as stencil (reference:
 src/boltzmann_c_solver.c:370-372), and that lattice is the one the PREVIOUS
 sweep wrote.  Ranks form a non-periodic chain: rank r talks to r-1 and r+1.
-A slab keeps G = 2 ghost columns per side; owned columns are G .. G+W-1.
+A slab keeps G = 4 ghost columns per side; owned columns are G .. G+W-1.
 
-Two step forms, bit-identical to each other and to a single-domain run:
+Three step forms, bit-identical to each other and to a single-domain run:
 
 * ``step()``  -- the reference's two sweeps, each as
       edge columns -> pack 1 column -> send/recv -> interior columns -> wait -> unpack
@@ -19,7 +19,15 @@ Two step forms, bit-identical to each other and to a single-domain run:
   ONE exchange per step:
       edge ranges -> pack 2 columns -> send/recv -> interior range -> wait -> unpack
 
-Either way the ~1-4 KB messages travel while the interior is being updated.
+* ``double_step()`` -- two loop iterations (four sweeps) in one launch per column
+  range.  A slab recomputes the three earlier sweeps up to three columns into
+  its ghost zone; afterwards the new main lattice (3 columns) and the new
+  half-step lattice (4 columns) travel, ONE exchange per TWO steps:
+      edge ranges -> pack -> send/recv -> interior range -> wait -> unpack
+
+Either way the few-KB messages travel while the interior is being updated.
+After every step form all G ghost columns of both current lattices are valid,
+so the forms can be mixed freely.
 All arithmetic stays in the engine (the HIP kernels); this file only orders
 launches and moves 2*ncols*(N+1) floats per side.
 """
@@ -54,6 +62,15 @@ class HipEngine:
     def step_fused_range(self, j2_first, j2_last, cosines):
         self.sol.step_fused_range(j2_first, j2_last, cosines)
 
+    def cosines2(self):
+        return self.slb.step2_cosines(self.sol.s.t)
+
+    def double_step_range(self, j_first, j_last, cosines8):
+        self.sol.double_step_range(j_first, j_last, cosines8)
+
+    def double_step_finish(self):
+        self.sol.double_step_finish()
+
     def pack(self, which, side, ncols, buf):
         self.sol.halo_pack(which, side, ncols, buf.data_ptr())
 
@@ -80,8 +97,8 @@ class SlabRun:
         self.left = rank - 1 if rank > 0 else None
         self.right = rank + 1 if rank < world - 1 else None
         # [ncols][side] send / receive buffers
-        self.send = {n: [self.eng.new_buffer(n), self.eng.new_buffer(n)] for n in (1, 2)}
-        self.recv = {n: [self.eng.new_buffer(n), self.eng.new_buffer(n)] for n in (1, 2)}
+        self.send = {n: [self.eng.new_buffer(n), self.eng.new_buffer(n)] for n in (1, 2, 3, 4)}
+        self.recv = {n: [self.eng.new_buffer(n), self.eng.new_buffer(n)] for n in (1, 2, 3, 4)}
         self.cpu_staging = dist.is_initialized() and dist.get_backend(group) == "gloo"
 
     # -- halo exchange of lattice `which` (see slb_solver_halo_pack) ----------
@@ -131,20 +148,25 @@ class SlabRun:
         e.sweep_range(lattice, lo, hi, c0, c1)
         self._finish_exchange(which_out, pending)
 
+    def _refresh_ghosts(self):
+        """All ghost columns of the current main lattice (3 are ever read) and of
+        the current half-step lattice (4), so that any step form may follow."""
+        self.exchange(3, 3)
+        self.exchange(0, 4)
+
     def tiptoe(self):
         """First half step; afterwards the half-step lattice's ghost columns are
-        brought up to date (both of them, so that either step form can follow)."""
+        brought up to date (the main lattice's are from the initial state)."""
         self.eng.tiptoe()
-        self.exchange(0, 2)
+        self.exchange(0, 4)
 
     def step(self):
         c = self.eng.cosines()
         self._sweep(0, 1, 1, c[0], c[1])   # main lattice: writes a/b[next], ships 1 edge column
-        # half-step lattice: writes a/b[next_hs]; 2 edge columns travel so that a
-        # one-launch step may follow a two-sweep step
-        self._sweep(1, 2, 2, c[2], c[3])
+        self._sweep(1, 2, 1, c[2], c[3])   # half-step lattice: writes a/b[next_hs]
         self.eng.swap()
         self.eng.advance()
+        self._refresh_ghosts()
 
     # -- one-launch form -------------------------------------------------------
     def step_fused(self):
@@ -163,6 +185,27 @@ class SlabRun:
         self._finish_exchange(2, pending)
         e.swap()
         e.advance()
+        self._refresh_ghosts()
+
+    # -- two iterations per launch ----------------------------------------------
+    def double_step(self):
+        e = self.eng
+        c = e.cosines2()
+        first, last_owned = e.G, e.G + e.W - 1
+        lo, hi = first, last_owned
+        if self.left is not None:
+            e.double_step_range(first, first + 3, c)
+            lo = first + 4
+        if self.right is not None:
+            e.double_step_range(last_owned - 3, last_owned, c)
+            hi = last_owned - 4
+        # the edge columns of both new lattices sit in the spare arrays (4 = main, 5 = half-step)
+        pend_main = self._start_exchange(4, 3)
+        pend_half = self._start_exchange(5, 4)
+        e.double_step_range(lo, hi, c)
+        self._finish_exchange(4, pend_main)
+        self._finish_exchange(5, pend_half)
+        e.double_step_finish()                       # the spares become the current lattices
 
     def close(self):
         self.eng.close()

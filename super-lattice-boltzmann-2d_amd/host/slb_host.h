@@ -97,6 +97,13 @@ void slb_solver_step_fused_range(slb_solver *s, int j2_first, int j2_last, const
  * call allocates four spare arrays.  Same state afterwards as two
  * slb_solver_step() calls, bit for bit (ping-pong indices included). */
 void slb_solver_double_step(slb_solver *s);
+/* the same in pieces, for drivers that overlap a halo exchange: the launch for
+ * the last sweep's columns j_first..j_last (results go to the spare arrays),
+ * then the hand-over of the spares and the time advance */
+void slb_solver_double_step_range(slb_solver *s, int j_first, int j_last, const float c[8]);
+void slb_solver_double_step_finish(slb_solver *s);
+/* cosines of two consecutive iterations starting at t (see slb_step_cosines) */
+void slb_step2_cosines(float t, float c[8]);
 
 /* `steps` iterations bracketed by HIP events on the launch stream; *ms gets the
  * elapsed device time.  Single slab. */
@@ -105,10 +112,11 @@ int slb_solver_run_timed(slb_solver *s, int steps, float *ms);
 /* halo columns of a lattice that a sweep reads as stencil.
  * which: 0 = a/b[current_hs] (stencil of the main sweep),
  *        1 = a/b[next]       (output of the main sweep, stencil of the half sweep),
- *        2 = a/b[next_hs]    (output of the half sweep, next step's current_hs).
+ *        2 = a/b[next_hs]    (output of the half sweep, next step's current_hs),
+ *        3 = a/b[current], 4 / 5 = the double step's spare main / half-step lattice.
  * side:  0 = left neighbour (send my first ncols owned columns, receive into the
  *            ncols ghost columns left of them), 1 = right neighbour likewise.
- * ncols: 1 for the sweep-by-sweep form, 2 for the one-launch step.
+ * ncols: 1..G.
  * buf holds 2*ncols*(N+1) floats (device). */
 int slb_solver_halo_pack  (slb_solver *s, int which, int side, int ncols, float *buf);
 int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const float *buf);

@@ -71,14 +71,14 @@ slb_solver *slb_solver_create(int rank, int nranks)
   /* columns 1..M are dealt out in contiguous runs; the last slab also carries
    * column M+1 of the main lattice and the boundary column M+2.  A slab keeps
    * G ghost columns per side: 1 for a single slab (the reference layout, the
-   * ghosts are the boundary columns 0 and M+2), 2 when there are neighbours, so
-   * that the one-launch step can recompute the main sweep one column into the
-   * ghost zone and needs one exchange per step. */
+   * ghosts are the boundary columns 0 and M+2), 4 when there are neighbours, so
+   * that the fused steps can recompute the earlier sweeps up to three columns
+   * into the ghost zone and need one exchange per launch. */
   const int base = host_M / nranks, rem = host_M % nranks;
   s->W = base + (rank < rem ? 1 : 0);
-  s->G = nranks == 1 ? 1 : 2;
-  if (nranks > 1 && s->W < 4) {
-    fprintf(stderr, "slb_solver_create: slabs need at least 4 columns each\n");
+  s->G = nranks == 1 ? 1 : 4;
+  if (nranks > 1 && s->W < 8) {
+    fprintf(stderr, "slb_solver_create: slabs need at least 8 columns each\n");
     free(s);
     return NULL;
   }
@@ -112,7 +112,7 @@ slb_solver *slb_solver_create(int rank, int nranks)
   HIP_OK(hipMalloc((void **)&s->av_data, 6 * sizeof(float)));
   HIP_OK(hipMemset(s->av_data, 0, 6 * sizeof(float)));
   HIP_OK(hipMalloc((void **)&s->sums, 4 * sizeof(double)));
-  HIP_OK(hipMalloc((void **)&s->halo_buf, (size_t)16 * (s->N + 1) * sizeof(float)));
+  HIP_OK(hipMalloc((void **)&s->halo_buf, (size_t)32 * (s->N + 1) * sizeof(float)));
   HIP_OK(hipDeviceSynchronize());
 
   s->current = 0; s->next = 1; s->current_hs = 2; s->next_hs = 3;
@@ -267,23 +267,42 @@ static void sync_spares(slb_solver *s)
   s->spare_of = s->current; s->spare_of_hs = s->current_hs;
 }
 
-void slb_solver_double_step(slb_solver *s)
+/* Double step for the columns j_first..j_last of the LAST sweep (half-step
+ * lattice at t+5dt/2), clipped to the slab's own; each earlier sweep is formed
+ * one column further out per stage, as far as this slab may: into its ghost
+ * zone next to a neighbour, not into a global boundary column.  Results go to
+ * the spare arrays; slb_solver_double_step_finish() makes them current.
+ * c[0..3] = cosines of the first iteration, c[4..7] of the second. */
+void slb_solver_double_step_range(slb_solver *s, int j_first, int j_last, const float c[8])
 {
   if (!s->spare_a || s->spare_of != s->current || s->spare_of_hs != s->current_hs) sync_spares(s);
-  float c[8];
-  slb_step_cosines(s->t, c);
-  const float t2 = s->t + host_dt;              /* the loop variable after one iteration */
-  slb_step_cosines(t2, c + 4);
+  const int G = s->G, first = s->rank == 0, last = s->rank == s->nranks - 1;
+  /* outermost columns stage q (0 = A .. 3 = D) may form in this slab */
+  int lo[4], hi[4];
+  for (int q = 0; q < 4; q++) {
+    lo[q] = first ? G : G - 3 + q;
+    const int main_sweep = (q % 2) == 0;
+    hi[q] = last ? G + s->W - 1 + (main_sweep ? 1 : 0) : G + s->W - 1 + 3 - q;
+  }
   slb_step2_geom g;
   g.pitch = s->pitch; g.m_offset = s->m_offset;
-  g.j_first[0] = g.j_first[2] = s->main_slab.j_first; g.j_last[0] = g.j_last[2] = s->main_slab.j_last;
-  g.j_first[1] = g.j_first[3] = s->half_slab.j_first; g.j_last[1] = g.j_last[3] = s->half_slab.j_last;
+  g.j_first[3] = j_first > lo[3] ? j_first : lo[3];
+  g.j_last[3]  = j_last  < hi[3] ? j_last  : hi[3];
+  if (g.j_last[3] < g.j_first[3]) return;
+  for (int q = 2; q >= 0; q--) {
+    g.j_first[q] = g.j_first[q + 1] - 1 > lo[q] ? g.j_first[q + 1] - 1 : lo[q];
+    g.j_last[q]  = g.j_last[q + 1] + 1 < hi[q] ? g.j_last[q + 1] + 1 : hi[q];
+  }
   check_sweep(slb_step_fused2(&g, s->a0, s->a[s->current], s->b[s->current],
                               s->a[s->current_hs], s->b[s->current_hs],
                               s->a[s->next], s->b[s->next], s->a[s->next_hs], s->b[s->next_hs],
                               s->spare_a, s->spare_b, s->spare_ah, s->spare_bh, c), __LINE__);
-  /* after two iterations the ping-pong indices are back where they were; the
-   * arrays that now hold those lattices are the former spares */
+}
+
+/* after two iterations the ping-pong indices are back where they were; the
+ * arrays that now hold those lattices are the former spares */
+void slb_solver_double_step_finish(slb_solver *s)
+{
   float *x;
   x = s->a[s->current];    s->a[s->current]    = s->spare_a;  s->spare_a  = x;
   x = s->b[s->current];    s->b[s->current]    = s->spare_b;  s->spare_b  = x;
@@ -291,6 +310,21 @@ void slb_solver_double_step(slb_solver *s)
   x = s->b[s->current_hs]; s->b[s->current_hs] = s->spare_bh; s->spare_bh = x;
   slb_solver_advance(s);
   slb_solver_advance(s);
+}
+
+void slb_step2_cosines(float t, float c[8])
+{
+  slb_step_cosines(t, c);
+  const float t2 = t + host_dt;                 /* the loop variable after one iteration */
+  slb_step_cosines(t2, c + 4);
+}
+
+void slb_solver_double_step(slb_solver *s)
+{
+  float c[8];
+  slb_step2_cosines(s->t, c);
+  slb_solver_double_step_range(s, s->half_slab.j_first, s->half_slab.j_last, c);
+  slb_solver_double_step_finish(s);
 }
 
 int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
@@ -316,25 +350,34 @@ int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
   return 0;
 }
 
-static int halo_array(const slb_solver *s, int which)
+/* which: 0 a/b[current_hs], 1 a/b[next], 2 a/b[next_hs], 3 a/b[current],
+ *        4 spare main lattice, 5 spare half-step lattice */
+static void halo_arrays(const slb_solver *s, int which, float **a, float **b)
 {
-  return which == 0 ? s->current_hs : (which == 1 ? s->next : s->next_hs);
+  if (which == 4)      { *a = s->spare_a;  *b = s->spare_b; }
+  else if (which == 5) { *a = s->spare_ah; *b = s->spare_bh; }
+  else {
+    const int idx = which == 0 ? s->current_hs : which == 1 ? s->next : which == 2 ? s->next_hs : s->current;
+    *a = s->a[idx]; *b = s->b[idx];
+  }
 }
 
 int slb_solver_halo_pack(slb_solver *s, int which, int side, int ncols, float *buf)
 {
-  const int idx = halo_array(s, which);
-  if (ncols < 1 || ncols > s->G) return -1;
+  float *a, *b;
+  halo_arrays(s, which, &a, &b);
+  if (ncols < 1 || ncols > s->G || !a) return -1;
   const int col = side == 0 ? s->G : s->G + s->W - ncols;       /* my outermost owned columns */
-  return slb_halo_pack(s->a[idx], s->b[idx], s->pitch, s->N + 1, col, ncols, buf);
+  return slb_halo_pack(a, b, s->pitch, s->N + 1, col, ncols, buf);
 }
 
 int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const float *buf)
 {
-  const int idx = halo_array(s, which);
-  if (ncols < 1 || ncols > s->G) return -1;
+  float *a, *b;
+  halo_arrays(s, which, &a, &b);
+  if (ncols < 1 || ncols > s->G || !a) return -1;
   const int col = side == 0 ? s->G - ncols : s->G + s->W;       /* the ghost columns next to them */
-  return slb_halo_unpack(s->a[idx], s->b[idx], s->pitch, s->N + 1, col, ncols, buf);
+  return slb_halo_unpack(a, b, s->pitch, s->N + 1, col, ncols, buf);
 }
 
 int slb_solver_get_rows(slb_solver *s, int arr, int row0, int nrows, float *dst)

@@ -29,7 +29,7 @@ class OracleEngine:
         self.ob, self.p, self.rank, self.world = ob, p, rank, world
         self.N = p.N
         self.W, first = slab_columns(p.M, rank, world)
-        self.G = 1 if world == 1 else 2
+        self.G = 1 if world == 1 else 4
         G = self.G
         self.m_offset = first - G
         self.pitch = self.W + 2 * G + 1
@@ -80,9 +80,6 @@ class OracleEngine:
             self._sweep(max(j_first, self.G), j_last, self.a[self.cur_hs], self.b[self.cur_hs],
                         self.a[self.nxt], self.b[self.nxt], self.a[self.nxt_hs], self.b[self.nxt_hs], c0, c1)
 
-    def _idx(self, which):
-        return (self.cur_hs, self.nxt, self.nxt_hs)[which]
-
     def step_fused_range(self, j2_first, j2_last, c):
         """Same contract as slb_solver_step_fused_range, done as two oracle sweeps."""
         G = self.G
@@ -95,19 +92,67 @@ class OracleEngine:
         self._sweep(j2_first, j2_last, self.a[self.cur_hs], self.b[self.cur_hs],
                     self.a[self.nxt], self.b[self.nxt], self.a[self.nxt_hs], self.b[self.nxt_hs], c[2], c[3])
 
+    def _pair(self, which):
+        if which == 4:
+            return self.sp_a, self.sp_b
+        if which == 5:
+            return self.sp_ah, self.sp_bh
+        i = (self.cur_hs, self.nxt, self.nxt_hs, self.cur)[which]
+        return self.a[i], self.b[i]
+
     def pack(self, which, side, ncols, buf):
-        i = self._idx(which)
         col = self.G if side == 0 else self.G + self.W - ncols
-        parts = [arr[i][:, col + c] for arr in (self.a, self.b) for c in range(ncols)]
+        parts = [arr[:, col + c] for arr in self._pair(which) for c in range(ncols)]
         buf.copy_(self.torch.from_numpy(np.concatenate(parts)))
 
     def unpack(self, which, side, ncols, buf):
-        i = self._idx(which)
         col = self.G - ncols if side == 0 else self.G + self.W
         v = buf.numpy().reshape(2, ncols, self.N + 1)
-        for q, arr in enumerate((self.a, self.b)):
+        for q, arr in enumerate(self._pair(which)):
             for c in range(ncols):
-                arr[i][:, col + c] = v[q, c]
+                arr[:, col + c] = v[q, c]
+
+    # -- double step, same contract as slb_solver_double_step_range / _finish ----
+    def cosines2(self):
+        c = self.cosines()
+        t = self.t
+        self.t = np.float32(t + np.float32(self.p.dt))
+        c2 = self.cosines()
+        self.t = t
+        return c + c2
+
+    def double_step_range(self, j_first, j_last, c):
+        if getattr(self, "sp_of", None) != (self.cur, self.cur_hs):
+            self.sp_a, self.sp_b = self.a[self.cur].copy(), self.b[self.cur].copy()
+            self.sp_ah, self.sp_bh = self.a[self.cur_hs].copy(), self.b[self.cur_hs].copy()
+            self.sp_of = (self.cur, self.cur_hs)
+        G, W = self.G, self.W
+        first, last = self.rank == 0, self.rank == self.world - 1
+        lo = [G if first else G - 3 + q for q in range(4)]
+        hi = [(G + W - 1 + (1 if q % 2 == 0 else 0)) if last else G + W - 1 + 3 - q for q in range(4)]
+        jf, jl = [0] * 4, [0] * 4
+        jf[3], jl[3] = max(j_first, lo[3]), min(j_last, hi[3])
+        if jl[3] < jf[3]:
+            return
+        for q in (2, 1, 0):
+            jf[q], jl[q] = max(jf[q + 1] - 1, lo[q]), min(jl[q + 1] + 1, hi[q])
+        # the in-between lattices start from the buffers that would receive them, so every
+        # cell their sweeps do not write is what the reference finds there
+        o1a, o1b = self.a[self.nxt].copy(), self.b[self.nxt].copy()
+        o2a, o2b = self.a[self.nxt_hs].copy(), self.b[self.nxt_hs].copy()
+        self._sweep(jf[0], jl[0], self.a[self.cur], self.b[self.cur], self.a[self.cur_hs], self.b[self.cur_hs],
+                    o1a, o1b, c[0], c[1])
+        self._sweep(jf[1], jl[1], self.a[self.cur_hs], self.b[self.cur_hs], o1a, o1b, o2a, o2b, c[2], c[3])
+        self._sweep(jf[2], jl[2], o1a, o1b, o2a, o2b, self.sp_a, self.sp_b, c[4], c[5])
+        self._sweep(jf[3], jl[3], o2a, o2b, self.sp_a, self.sp_b, self.sp_ah, self.sp_bh, c[6], c[7])
+
+    def double_step_finish(self):
+        self.a[self.cur], self.sp_a = self.sp_a, self.a[self.cur]
+        self.b[self.cur], self.sp_b = self.sp_b, self.b[self.cur]
+        self.a[self.cur_hs], self.sp_ah = self.sp_ah, self.a[self.cur_hs]
+        self.b[self.cur_hs], self.sp_bh = self.sp_bh, self.b[self.cur_hs]
+        self.advance()
+        self.advance()
 
     def swap(self):
         self.cur, self.nxt = self.nxt, self.cur
