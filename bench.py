@@ -95,9 +95,13 @@ def main():
         sol = slb.Solver(0, 1)
         sol.tiptoe()
         sol.set_fused({"double": 2, "fused": 1, "sweeps": 0}[args.form])
+        warm = args.warmup
         if args.form == "double":
+            # an even number of warm-up steps keeps the ping-pong parity the spare arrays were
+            # made for (an odd count would re-copy them inside the timed region)
+            warm += warm % 2
             sol.double_step()                    # allocates the spare arrays outside the timed region
-        sol.run_timed(args.warmup)
+        sol.run_timed(warm)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev_ms = sol.run_timed(args.steps)        # HIP events on the launch stream
@@ -121,7 +125,7 @@ def main():
             for _ in range(nsteps - k):
                 (run.step if args.form == "sweeps" else run.step_fused)()
 
-        advance(max(args.warmup, 2))
+        advance(max(args.warmup + args.warmup % 2, 2))
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()

@@ -127,7 +127,7 @@ def test_program_config1_matches_recorded_reference_line(solver_bin, tmp_path):
     import json
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
                                        "config1_display4_reference.json")))
-    for form in ("fused", "sweeps"):
+    for form in ("double", "fused", "sweeps"):
         r = subprocess.run([solver_bin] + gold["args"].split() + ["o=out.txt"], cwd=tmp_path,
                            capture_output=True, text=True, timeout=600, env=dict(os.environ, SLB_FORM=form))
         assert r.returncode == 0, r.stdout + r.stderr
