@@ -150,6 +150,29 @@ int slb_step_fused2(const slb_step2_geom *geom, const float *a0,
                     float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
                     const float cosines[8]);
 
+/* Geometry of S = `steps` loop iterations in one launch (1 <= S <= 4): the
+ * columns each of the 2S sweeps produces, in execution order (main sweep at t,
+ * half-step sweep at t, main sweep at t+dt, ...). */
+typedef struct slb_multi_geom {
+  int pitch, m_offset, steps;
+  int j_first[8], j_last[8];
+} slb_multi_geom;
+
+/* S loop iterations in one launch, the general form of slb_step_fused (S=1) and
+ * slb_step_fused2 (S=2); bit-identical to 2S separate sweeps.
+ *   in[4]     = a_current, b_current, a_current_hs, b_current_hs
+ *   out[4]    = main lattice after S iterations (a, b), half-step lattice (a, b);
+ *               must not alias `in`
+ *   pers_a/pers_b[q], q = 0..2S-2: for sweep q, the arrays that hold -- at the
+ *               cells no sweep writes -- what the reference's ping-pong buffers
+ *               hold where sweep q's output would go (a/b[next], a/b[next_hs],
+ *               a/b[current], a/b[current_hs], a/b[next], ...); entry 2S-2 is out[0..1]
+ *   cosines[4S]: slb_step_cosines() of the S loop times, concatenated.
+ * Only the last two sweeps' outputs are stored.  Returns like slb_sweep. */
+int slb_step_multi(const slb_multi_geom *geom, const float *a0, const float *const in[4],
+                   const float *const pers_a[], const float *const pers_b[], float *const out[4],
+                   const float cosines[]);
+
 /* Gather local columns col..col+ncols-1 of rows 0..nrows-1 of arrays a and b
  * into buf (a's columns first, each column contiguous: buf[(q*ncols + c)*nrows + r],
  * q = 0 for a, 1 for b); and the inverse scatter.  buf holds 2*ncols*nrows floats. */

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--blocks", default="256,128,64")
     ap.add_argument("--fused", action="store_true", help="time the one-launch step (variants 6, 7)")
     ap.add_argument("--double", action="store_true", help="time the double step (variants 21-25)")
+    ap.add_argument("--multi", type=int, default=0, help="time the S-steps-per-launch kernel (S = 1..4)")
     args = ap.parse_args()
     import torch
     slb = importlib.import_module("super-lattice-boltzmann-2d_amd")
@@ -30,11 +31,15 @@ def main():
     L = slb.lib()
     sol = slb.Solver()
     sol.tiptoe()
-    sol.set_fused(2 if args.double else args.fused)
-    per_launch = 0.5 if args.double else (1 if args.fused else 2)
-    bytes_per_point = 36.0 if (args.fused or args.double) else 28.0
-    if args.double:
-        sol.double_step()
+    sol.set_fused(10 + args.multi if args.multi else (2 if args.double else args.fused))
+    per_launch = 1.0 / args.multi if args.multi else (0.5 if args.double else (1 if args.fused else 2))
+    bytes_per_point = 36.0 if (args.fused or args.double or args.multi) else 28.0
+    if args.double or args.multi:
+        sol.multi_step(12 // (args.multi or 2))   # spares made, parity back to the start
+        for _ in range(12 // (args.multi or 2) - 1):
+            sol.multi_step(args.multi or 2)
+    if args.multi:
+        args.steps = args.steps // 12 * 12 or 12
     for v in [int(x) for x in args.variants.split(",")]:
         for nc in [int(x) for x in args.chunks.split(",")]:
             for b in [int(x) for x in args.blocks.split(",")]:

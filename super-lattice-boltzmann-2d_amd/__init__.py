@@ -23,7 +23,7 @@ _INT_GLOBALS = ("host_M", "host_N", "MSIZE", "MP1", "NSIZE", "host_TMSIZE", "PAD
 
 # every symbol include/slb_abi.h declares
 ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "HandleError",
-                 "slb_sweep", "slb_step_fused", "slb_step_fused2", "slb_halo_pack", "slb_halo_unpack", "slb_av_partial",
+                 "slb_sweep", "slb_step_fused", "slb_step_fused2", "slb_step_multi", "slb_halo_pack", "slb_halo_unpack", "slb_av_partial",
                  "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream",
                  "slb_set_tuning", "slb_version")
 ABI_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha",
@@ -115,6 +115,12 @@ def lib():
         L.slb_solver_double_step_range.restype = None
         L.slb_solver_double_step_finish.argtypes = [C.POINTER(SolverStruct)]
         L.slb_solver_double_step_finish.restype = None
+        L.slb_solver_multi_step.argtypes, L.slb_solver_multi_step.restype = [C.POINTER(SolverStruct), i], None
+        L.slb_solver_multi_step_range.argtypes = [C.POINTER(SolverStruct), i, i, i, C.POINTER(C.c_float)]
+        L.slb_solver_multi_step_range.restype = None
+        L.slb_solver_multi_step_finish.argtypes = [C.POINTER(SolverStruct), i]
+        L.slb_solver_multi_step_finish.restype = None
+        L.slb_steps_cosines.argtypes, L.slb_steps_cosines.restype = [f, i, C.POINTER(C.c_float)], None
         L.slb_step2_cosines.argtypes, L.slb_step2_cosines.restype = [f, C.POINTER(C.c_float * 8)], None
         L.slb_solver_step_fused_range.argtypes = [C.POINTER(SolverStruct), i, i, C.POINTER(C.c_float * 4)]
         L.slb_solver_step_fused_range.restype = None
@@ -193,6 +199,16 @@ class Solver:
     def double_step(self):
         lib().slb_solver_double_step(self._p)
 
+    def multi_step(self, S):
+        lib().slb_solver_multi_step(self._p, S)
+
+    def multi_step_range(self, S, j_first, j_last, cosines):
+        c = (C.c_float * (4 * S))(*cosines)
+        lib().slb_solver_multi_step_range(self._p, S, j_first, j_last, c)
+
+    def multi_step_finish(self, S):
+        lib().slb_solver_multi_step_finish(self._p, S)
+
     def double_step_range(self, j_first, j_last, cosines8):
         c = (C.c_float * 8)(*cosines8)
         lib().slb_solver_double_step_range(self._p, j_first, j_last, C.byref(c))
@@ -261,6 +277,12 @@ class Solver:
         if rc:
             raise RuntimeError(f"slb_solver_get_window -> {rc}")
         return out
+
+
+def steps_cosines(t, S):
+    c = (C.c_float * (4 * S))()
+    lib().slb_steps_cosines(t, S, c)
+    return tuple(c)
 
 
 def step2_cosines(t):

@@ -816,6 +816,171 @@ fused2_step_kernel(const Fused2Args p)
 }
 
 // ---------------------------------------------------------------------------
+// S loop iterations (2S sweeps) in one pass: the general form of the two
+// kernels above.  Stage q (0 = main sweep at t, 1 = half-step sweep at t,
+// 2 = main sweep at t+dt, ...) runs at row r-q when stage 0 stands at row r.
+// Its centre is the output of stage q-2 two iterations ago, its stencil the
+// output of stage q-1 of this iteration (row n+1) and of two iterations ago
+// (row n-1); stages 0 and 1 take the input lattices instead.  Every stage keeps
+// its last two output rows in registers; only the last two stages store.
+// Each hand-off costs one column of validity per side of a wave, so
+// H = ceil((2S-1)/4) halo lanes per side recompute what the neighbouring wave owns.
+// pers_a/pers_b[q]: the array whose never-written cells (row N, boundary
+// columns) stage q's output inherits -- where the reference's ping-pong would
+// have put that lattice; for stage 2S-2 that is its own output array.
+// ---------------------------------------------------------------------------
+template <int S>
+struct MultiArgs {
+  static constexpr int Q = 2 * S;
+  const float *a0, *a_c, *b_c, *a_h, *b_h;
+  const float *pers_a[Q - 1], *pers_b[Q - 1];
+  float *a_o, *b_o, *a_ho, *b_ho;            // outputs of stage Q-2 (main) and Q-1 (half-step)
+  float E_dc, E_omega, B, dt, dPhi, PhiYmin, nu, nu2, nu_tilde, bdt;
+  float c[2 * Q];                            // cosines, two per stage
+  int N, pitch, m_offset, n_chunk, jj0;
+  int jf[Q], jl[Q];                          // columns each stage produces
+};
+
+template <int S, int MINW, bool DIAG = false>
+__global__ void __launch_bounds__(256, MINW)
+multi_step_kernel(const MultiArgs<S> p)
+{
+  constexpr int V = 4, Q = 2 * S, H = (Q - 1 + 3) / 4, INNER = 64 - 2 * H;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int jj   = p.jj0 + (wave * INNER + lane - H) * V;       // first own column (may be < 0)
+  int j_hi = p.jl[0];
+#pragma unroll
+  for (int q = 1; q < Q; q++) j_hi = p.jl[q] > j_hi ? p.jl[q] : j_hi;
+  if (p.jj0 + wave * INNER * V > j_hi) return;                  // whole wave past the end
+  const bool interior = lane >= H && lane < 64 - H;
+  const int jcl = jj < 0 ? 0 : (jj > p.pitch - V ? p.pitch - V : jj);
+  const unsigned j = (unsigned)jcl;
+
+  const int n0 = blockIdx.y * p.n_chunk;
+  const int n1 = n0 + p.n_chunk < p.N ? n0 + p.n_chunk : p.N;
+  const int a_lo  = n0 > Q - 1 ? n0 - (Q - 1) : 0;              // first row of stage 0
+  const int r_end = n1 + Q - 2;                                 // last stage forms row n1-1 then
+
+  float bphi[V];
+  unsigned ok = 0;          // bit q*4+k: stage q produces column k (stages 0..Q-2)
+  unsigned wr = 0;          // bit k: stage Q-2 stores column k; bit 4+k: stage Q-1 stores it
+  unsigned need = 0;        // bit q: this lane must fetch never-written cells for stage q
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    const int c = jj + k;
+    bphi[k] = p.B * (p.PhiYmin + p.dPhi * (float)(p.m_offset + c - 1));
+    const bool in_row = c >= 0 && c < p.pitch;
+#pragma unroll
+    for (int q = 0; q < Q - 1; q++) {
+      const bool okq = c >= p.jf[q] && c <= p.jl[q];
+      if (okq) ok |= 1u << (q * 4 + k);
+      // a column the next stage reads at m+-1 that this stage does not produce keeps its old value
+      if (!okq && in_row && c >= p.jf[q + 1] - 1 && c <= p.jl[q + 1] + 1) need |= 1u << q;
+    }
+    if (interior && c >= p.jf[Q - 2] && c <= p.jl[Q - 2]) wr |= 1u << k;
+    if (interior && c >= p.jf[Q - 1] && c <= p.jl[Q - 1]) wr |= 1u << (4 + k);
+  }
+  if (jj != jcl) need = 0;
+  float sc[2 * Q];
+#pragma unroll
+  for (int q = 0; q < 2 * Q; q++) sc[q] = p.E_dc + p.E_omega * p.c[q];
+
+  const size_t P = (size_t)p.pitch;
+  auto load4 = [&](const float *base, size_t row, float (&v)[V]) {
+    const float4 x = *reinterpret_cast<const float4 *>(base + row + j);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  };
+  auto diffs = [&](const float (&own)[V], float (&d)[V]) {
+    float e[6];
+    widen(own, e);
+#pragma unroll
+    for (int k = 0; k < V; k++) d[k] = e[k + 2] - e[k];
+  };
+
+  // histories: index 0 = one iteration ago, 1 = two iterations ago
+  float hA[2][V] = {}, hB[2][V] = {};               // input half-step lattice rows r, r-1
+  float oA[Q - 1][2][V] = {}, oB[Q - 1][2][V] = {}; // stage outputs
+  float a0h[Q - 1][V] = {};                         // a0 rows r-1 .. r-(Q-1)
+
+  if (a_lo >= 1) { load4(p.a_h, (size_t)(a_lo - 1) * P, hA[1]); load4(p.b_h, (size_t)(a_lo - 1) * P, hB[1]); }
+  load4(p.a_h, (size_t)a_lo * P, hA[0]); load4(p.b_h, (size_t)a_lo * P, hB[0]);
+
+  for (int r = a_lo; r <= r_end; r++) {
+    float nA[Q][V] = {}, nB[Q][V] = {};             // this iteration's stage outputs
+    float a0r[V] = {}, inA[V] = {}, inB[V] = {}, upA0[V] = {}, upB0[V] = {};
+    if (r < p.N) {
+      const size_t row = (size_t)r * P;
+      load4(p.a0, row, a0r); load4(p.a_c, row, inA); load4(p.b_c, row, inB);
+      load4(p.a_h, row + P, upA0); load4(p.b_h, row + P, upB0);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const int n = r - q;
+      const int lo_q = n0 > Q - 1 - q ? n0 - (Q - 1 - q) : 0;
+      if (n >= lo_q && n < p.N) {
+        float ea[6], eb[6], dla[V], dlb[V];
+        // stencil: row n+1 (this iteration) with its m+-1 neighbours, row n-1 as differences
+        if (q == 0) { widen(upA0, ea); widen(upB0, eb); diffs(hA[1], dla); diffs(hB[1], dlb); }
+        else        { widen(nA[q - 1], ea); widen(nB[q - 1], eb); diffs(oA[q - 1][1], dla); diffs(oB[q - 1][1], dlb); }
+        const float fn = (float)n;
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+          const float ca = q == 0 ? inA[k] : (q == 1 ? hA[1][k] : oA[q - 2][1][k]);
+          const float cb = q == 0 ? inB[k] : (q == 1 ? hB[1][k] : oB[q - 2][1][k]);
+          const float a0v = q == 0 ? a0r[k] : a0h[q - 1][k];
+          const float mu_a = (sc[2 * q] + bphi[k]) * p.dt / 2.0f, mu_b = (sc[2 * q + 1] + bphi[k]) * p.dt / 2.0f;
+          point_update_sel<DIAG>(p, n, fn, mu_a, mu_b, a0v, ca, cb,
+                                 ea[k + 2], ea[k], eb[k + 2], eb[k], dla[k], dlb[k], nA[q][k], nB[q][k]);
+        }
+        const size_t row = (size_t)n * P;
+        if (q >= Q - 2 && n >= n0 && n < n1) {
+          float *da = q == Q - 2 ? p.a_o : p.a_ho, *db = q == Q - 2 ? p.b_o : p.b_ho;
+          const unsigned w = q == Q - 2 ? (wr & 0xfu) : (wr >> 4);
+          if (w == 0xfu) {
+            st4<false>(da + row, j, nA[q]);
+            if (n > 0) st4<false>(db + row, j, nB[q]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+              if (w & (1u << k)) {
+                da[row + j + k] = nA[q][k];
+                if (n > 0) db[row + j + k] = nB[q][k];
+              }
+            }
+          }
+        }
+        if (q < Q - 1) {
+          if (need & (1u << q)) {
+            float xa[V], xb[V];
+            load4(p.pers_a[q], row, xa); load4(p.pers_b[q], row, xb);
+#pragma unroll
+            for (int k = 0; k < V; k++)
+              if (!(ok & (1u << (q * 4 + k)))) { nA[q][k] = xa[k]; nB[q][k] = xb[k]; }
+          }
+        }
+      } else if (q < Q - 1 && n == p.N) {
+        // row N is never written: the stage's "output" there is what its buffer holds
+        load4(p.pers_a[q], (size_t)n * P, nA[q]); load4(p.pers_b[q], (size_t)n * P, nB[q]);
+      }
+    }
+    // ---- slide every history one row up ----
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+#pragma unroll
+      for (int q = 0; q < Q - 1; q++) {
+        oA[q][1][k] = oA[q][0][k]; oB[q][1][k] = oB[q][0][k];
+        oA[q][0][k] = nA[q][k];    oB[q][0][k] = nB[q][k];
+      }
+#pragma unroll
+      for (int q = Q - 2; q >= 1; q--) a0h[q][k] = a0h[q - 1][k];
+      a0h[0][k] = a0r[k];
+      hA[1][k] = hA[0][k]; hB[1][k] = hB[0][k]; hA[0][k] = upA0[k]; hB[0][k] = upB0[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // halo movers: one column of rows 0..nrows-1 of two arrays <-> contiguous buffer
 // ---------------------------------------------------------------------------
 // buf[(q*ncols + c)*nrows + r] <-> array q (0 = a, 1 = b), row r, column col + c
@@ -1017,6 +1182,35 @@ int launch_fused2(Fused2Args &args, int block)
   return (int)hipGetLastError();
 }
 
+template <int S, int MINW, bool DIAG = false>
+int launch_multi(const slb_multi_geom *g, const float *a0, const float *const *in, const float *const *pers_a,
+                 const float *const *pers_b, float *const *out, const float *cosines, int block, int n_chunk)
+{
+  constexpr int Q = 2 * S, H = (Q - 1 + 3) / 4, INNER = 64 - 2 * H;
+  MultiArgs<S> s;
+  s.a0 = a0; s.a_c = in[0]; s.b_c = in[1]; s.a_h = in[2]; s.b_h = in[3];
+  for (int q = 0; q < Q - 1; q++) { s.pers_a[q] = pers_a[q]; s.pers_b[q] = pers_b[q]; }
+  s.a_o = out[0]; s.b_o = out[1]; s.a_ho = out[2]; s.b_ho = out[3];
+  s.E_dc = g_phys.E_dc; s.E_omega = g_phys.E_omega; s.B = g_phys.B; s.dt = g_phys.dt;
+  s.dPhi = g_phys.dPhi; s.PhiYmin = g_phys.PhiYmin; s.nu = g_phys.nu; s.nu2 = g_phys.nu2;
+  s.nu_tilde = g_phys.nu_tilde; s.bdt = g_phys.bdt;
+  for (int q = 0; q < 2 * Q; q++) s.c[q] = cosines[q];
+  s.N = g_phys.N; s.pitch = g->pitch; s.m_offset = g->m_offset;
+  int lo = g->j_first[0], hi = g->j_last[0];
+  for (int q = 0; q < Q; q++) {
+    s.jf[q] = g->j_first[q]; s.jl[q] = g->j_last[q];
+    lo = s.jf[q] < lo ? s.jf[q] : lo; hi = s.jl[q] > hi ? s.jl[q] : hi;
+  }
+  s.jj0 = lo / 4 * 4;
+  s.n_chunk = n_chunk > s.N ? s.N : n_chunk;
+  const int per_wave = INNER * 4;
+  const int waves = (hi + 1 - s.jj0 + per_wave - 1) / per_wave;
+  const int wpb = block / 64;
+  dim3 grid((waves + wpb - 1) / wpb, (s.N + s.n_chunk - 1) / s.n_chunk);
+  hipLaunchKernelGGL((multi_step_kernel<S, MINW, DIAG>), grid, dim3(block), 0, g_stream, s);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1209,6 +1403,46 @@ int slb_step_fused2(const slb_step2_geom *g, const float *a0,
     case 25: return launch_fused2<false, 4>(s, block);
     case 98: return launch_fused2<false, 3, true>(s, block);   // timing only, wrong results
     default: return launch_fused2<false, 3>(s, block);
+  }
+}
+
+int slb_step_multi(const slb_multi_geom *g, const float *a0, const float *const in[4],
+                   const float *const pers_a[], const float *const pers_b[], float *const out[4],
+                   const float cosines[])
+{
+  if (!g_phys.loaded) { fprintf(stderr, "slb_step_multi: load_data() has not been called\n"); return -1; }
+  if (!g || g->steps < 1 || g->steps > 4 || g->pitch < 4 || g->pitch % 4 != 0 || g_phys.N < 1) {
+    fprintf(stderr, "slb_step_multi: bad geometry (1 to 4 steps per launch)\n");
+    return -1;
+  }
+  const int Q = 2 * g->steps;
+  for (int q = 0; q < Q; q++)
+    if (g->j_first[q] < 1 || g->j_last[q] > g->pitch - 2) { fprintf(stderr, "slb_step_multi: bad column range\n"); return -1; }
+  for (int i = 0; i < 4; i++) {
+    if (!aligned16(in[i]) || !aligned16(out[i])) { fprintf(stderr, "slb_step_multi: arrays must be 16-byte aligned\n"); return -1; }
+    for (int k = 0; k < 4; k++)
+      if (out[i] == in[k]) { fprintf(stderr, "slb_step_multi: outputs must not alias the inputs\n"); return -1; }
+  }
+  for (int q = 0; q < Q - 1; q++)
+    if (!aligned16(pers_a[q]) || !aligned16(pers_b[q])) { fprintf(stderr, "slb_step_multi: arrays must be 16-byte aligned\n"); return -1; }
+  if (!aligned16(a0)) return -1;
+  if (g->j_last[Q - 1] < g->j_first[Q - 1] && g->j_last[Q - 2] < g->j_first[Q - 2]) return 0;
+  const int block = g_block > 0 ? g_block : 256;
+  if (block % 64 != 0 || block > 256) { fprintf(stderr, "slb_step_multi: block must be 64, 128, 192 or 256\n"); return -1; }
+  const int n_chunk = g_n_chunk > 0 ? g_n_chunk : 64;
+  const int v = g_variant;
+  switch (g->steps) {
+    case 1: return v == 97 ? launch_multi<1, 4, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
+                           : launch_multi<1, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+    case 2: return v == 97 ? launch_multi<2, 3, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
+                 : v == 32 ? launch_multi<2, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
+                           : launch_multi<2, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+    case 3: return v == 97 ? launch_multi<3, 2, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
+                 : v == 33 ? launch_multi<3, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
+                           : launch_multi<3, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+    default: return v == 97 ? launch_multi<4, 2, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
+                  : v == 31 ? launch_multi<4, 1>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
+                            : launch_multi<4, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
   }
 }
 

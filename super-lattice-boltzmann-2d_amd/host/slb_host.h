@@ -102,6 +102,12 @@ void slb_solver_double_step(slb_solver *s);
  * then the hand-over of the spares and the time advance */
 void slb_solver_double_step_range(slb_solver *s, int j_first, int j_last, const float c[8]);
 void slb_solver_double_step_finish(slb_solver *s);
+/* S loop iterations per launch (1 <= S <= 4; slb_step_multi), whole slab */
+void slb_solver_multi_step(slb_solver *s, int S);
+void slb_solver_multi_step_range(slb_solver *s, int S, int j_first, int j_last, const float *c);
+void slb_solver_multi_step_finish(slb_solver *s, int S);
+/* cosines of S consecutive iterations starting at t, 4 per iteration */
+void slb_steps_cosines(float t, int S, float *c);
 /* cosines of two consecutive iterations starting at t (see slb_step_cosines) */
 void slb_step2_cosines(float t, float c[8]);
 

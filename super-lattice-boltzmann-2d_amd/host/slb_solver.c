@@ -327,6 +327,80 @@ void slb_solver_double_step(slb_solver *s)
   slb_solver_double_step_finish(s);
 }
 
+/* S loop iterations in one launch for the columns j_first..j_last of the LAST
+ * sweep; every earlier sweep reaches one column further out per stage, as far
+ * as this slab may form it.  Odd S: results go to a/b[next], a/b[next_hs];
+ * even S: to the spare arrays.  slb_solver_multi_step_finish() makes them
+ * current.  c = the cosines of the S loop times, 4 per iteration. */
+void slb_solver_multi_step_range(slb_solver *s, int S, int j_first, int j_last, const float *c)
+{
+  if (S < 1 || S > 4) { fprintf(stderr, "slb_solver_multi_step: 1 to 4 steps per launch\n"); exit(EXIT_FAILURE); }
+  const int Q = 2 * S, even = (S % 2) == 0;
+  if (even && (!s->spare_a || s->spare_of != s->current || s->spare_of_hs != s->current_hs)) sync_spares(s);
+  const int G = s->G, first = s->rank == 0, last = s->rank == s->nranks - 1;
+  if (s->nranks > 1 && Q > G) { fprintf(stderr, "slb_solver_multi_step: %d steps need %d ghost columns\n", S, Q); exit(EXIT_FAILURE); }
+  slb_multi_geom g;
+  memset(&g, 0, sizeof(g));
+  g.pitch = s->pitch; g.m_offset = s->m_offset; g.steps = S;
+  int lo[8], hi[8];
+  for (int q = 0; q < Q; q++) {
+    lo[q] = first ? G : G - (Q - 1 - q);
+    const int main_sweep = (q % 2) == 0;
+    hi[q] = last ? G + s->W - 1 + (main_sweep ? 1 : 0) : G + s->W - 1 + (Q - 1 - q);
+  }
+  g.j_first[Q - 1] = j_first > lo[Q - 1] ? j_first : lo[Q - 1];
+  g.j_last[Q - 1]  = j_last  < hi[Q - 1] ? j_last  : hi[Q - 1];
+  if (g.j_last[Q - 1] < g.j_first[Q - 1]) return;
+  for (int q = Q - 2; q >= 0; q--) {
+    g.j_first[q] = g.j_first[q + 1] - 1 > lo[q] ? g.j_first[q + 1] - 1 : lo[q];
+    g.j_last[q]  = g.j_last[q + 1] + 1 < hi[q] ? g.j_last[q + 1] + 1 : hi[q];
+  }
+  const float *in[4] = {s->a[s->current], s->b[s->current], s->a[s->current_hs], s->b[s->current_hs]};
+  float *out[4];
+  if (even) { out[0] = s->spare_a; out[1] = s->spare_b; out[2] = s->spare_ah; out[3] = s->spare_bh; }
+  else      { out[0] = s->a[s->next]; out[1] = s->b[s->next]; out[2] = s->a[s->next_hs]; out[3] = s->b[s->next_hs]; }
+  /* sweep q writes iteration i = q/2; the reference's iteration i writes the main lattice into
+   * `next` for even i and into `current` for odd i (likewise the half-step lattice) */
+  const float *pa[8], *pb[8];
+  for (int q = 0; q < Q - 1; q++) {
+    const int i = q / 2, into_next = (i % 2) == 0;
+    const int idx = (q % 2) == 0 ? (into_next ? s->next : s->current) : (into_next ? s->next_hs : s->current_hs);
+    pa[q] = s->a[idx]; pb[q] = s->b[idx];
+  }
+  pa[Q - 2] = out[0]; pb[Q - 2] = out[1];
+  check_sweep(slb_step_multi(&g, s->a0, in, pa, pb, out, c), __LINE__);
+}
+
+void slb_solver_multi_step_finish(slb_solver *s, int S)
+{
+  if (S % 2 == 0) {
+    float *x;
+    x = s->a[s->current];    s->a[s->current]    = s->spare_a;  s->spare_a  = x;
+    x = s->b[s->current];    s->b[s->current]    = s->spare_b;  s->spare_b  = x;
+    x = s->a[s->current_hs]; s->a[s->current_hs] = s->spare_ah; s->spare_ah = x;
+    x = s->b[s->current_hs]; s->b[s->current_hs] = s->spare_bh; s->spare_bh = x;
+  } else {
+    slb_solver_swap(s);
+  }
+  for (int i = 0; i < S; i++) slb_solver_advance(s);
+}
+
+void slb_steps_cosines(float t, int S, float *c)
+{
+  for (int i = 0; i < S; i++) {
+    slb_step_cosines(t, c + 4 * i);
+    t = t + host_dt;                          /* the loop variable, accumulated in float */
+  }
+}
+
+void slb_solver_multi_step(slb_solver *s, int S)
+{
+  float c[16];
+  slb_steps_cosines(s->t, S, c);
+  slb_solver_multi_step_range(s, S, s->half_slab.j_first, s->half_slab.j_last, c);
+  slb_solver_multi_step_finish(s, S);
+}
+
 int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
 {
   hipStream_t st = (hipStream_t)slb_get_stream();
@@ -336,8 +410,10 @@ int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
   HIP_OK(hipEventRecord(e0, st));
   int i = 0;
   if (s->fused == 2) {
-    /* warm the spares outside the timed region only when they are missing */
     for (; i + 1 < steps; i += 2) slb_solver_double_step(s);
+  } else if (s->fused >= 10) {               /* 10 + S: the general S-steps-per-launch kernel */
+    const int S = s->fused - 10;
+    for (; i + S <= steps; i += S) slb_solver_multi_step(s, S);
   }
   for (; i < steps; i++) {
     if (s->fused) slb_solver_step_fused(s); else slb_solver_step(s);
