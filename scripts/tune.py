@@ -35,8 +35,7 @@ def main():
     per_launch = 1.0 / args.multi if args.multi else (0.5 if args.double else (1 if args.fused else 2))
     bytes_per_point = 36.0 if (args.fused or args.double or args.multi) else 28.0
     if args.double or args.multi:
-        sol.multi_step(12 // (args.multi or 2))   # spares made, parity back to the start
-        for _ in range(12 // (args.multi or 2) - 1):
+        for _ in range(12 // (args.multi or 2)):   # spares made, ping-pong parity back to the start
             sol.multi_step(args.multi or 2)
     if args.multi:
         args.steps = args.steps // 12 * 12 or 12

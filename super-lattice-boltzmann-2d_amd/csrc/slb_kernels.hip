@@ -1431,18 +1431,14 @@ int slb_step_multi(const slb_multi_geom *g, const float *a0, const float *const 
   if (block % 64 != 0 || block > 256) { fprintf(stderr, "slb_step_multi: block must be 64, 128, 192 or 256\n"); return -1; }
   const int n_chunk = g_n_chunk > 0 ? g_n_chunk : 64;
   const int v = g_variant;
+  // waves per SIMD the register allocator is held to: measured best per S on MI355X
   switch (g->steps) {
-    case 1: return v == 97 ? launch_multi<1, 4, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
-                           : launch_multi<1, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+    case 1: return launch_multi<1, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
     case 2: return v == 97 ? launch_multi<2, 3, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
-                 : v == 32 ? launch_multi<2, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
                            : launch_multi<2, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
     case 3: return v == 97 ? launch_multi<3, 2, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
-                 : v == 33 ? launch_multi<3, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
                            : launch_multi<3, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
-    default: return v == 97 ? launch_multi<4, 2, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
-                  : v == 31 ? launch_multi<4, 1>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
-                            : launch_multi<4, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+    default: return launch_multi<4, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
   }
 }
 
