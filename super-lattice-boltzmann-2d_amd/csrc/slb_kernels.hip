@@ -1082,37 +1082,58 @@ __global__ void av_update_kernel(const double *sums, float *av_data, double cos_
     av_apply(av_data, (float)sums[0], (float)sums[1], (float)sums[2], cos_wt, sin_wt, dt);
 }
 
-// exact mode: wave q (q = 0,1,2) forms sum q by adding the terms one at a time
-// in float in column order, which is the reference's order of operations.
-// Lanes compute 64 terms in parallel; the additions run down the lanes.
-__global__ void __launch_bounds__(192) av_exact_kernel(const AvArgs p, float *av_data,
-                                                       double cos_wt, double sin_wt, float dt)
+// exact mode: workgroup q (one wave; q = 0,1,2) forms sum q by adding the terms
+// one at a time in float in column order, which is the reference's order of
+// operations.  The 64 lanes form 64 x T terms in parallel and park them in LDS
+// in column order (fetching the next 64 x T meanwhile); lane 0 then adds them
+// one after the other, four per 16-byte LDS read.  The chain of dependent
+// additions is the cost (about 8 cycles per column on gfx950), which is why the
+// three sums run as three workgroups: waves of one workgroup can end up on the
+// same SIMD and then take turns.  A one-lane kernel applies the update.
+__global__ void __launch_bounds__(64) av_exact_kernel(const AvArgs p, float *tot)
 {
-  __shared__ float tot[3];
-  const int q    = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
+  constexpr int T = 16, B = 64 * T;                  // columns per group
+  __shared__ __attribute__((aligned(16))) float park[B];
+  const int q    = blockIdx.x;
+  const int lane = threadIdx.x;
   float acc = 0.0f;
+  float term[T];
   int base = p.j_first;
-  float term = (base + lane <= p.j_last) ? av_term(p, q, base + lane) : 0.0f;
-  while (base <= p.j_last) {
-    const int nb = base + 64;
-    // fetch the next 64 terms while this batch is being added
-    const float next = (nb + lane <= p.j_last) ? av_term(p, q, nb + lane) : 0.0f;
-    const int valid = p.j_last - base + 1;
-    if (valid >= 64) {
 #pragma unroll
-      for (int k = 0; k < 64; k++)
-        acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, term), k));
-    } else {
-      for (int k = 0; k < valid; k++)
-        acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, term), k));
+  for (int t = 0; t < T; t++) {
+    const int j = base + t * 64 + lane;
+    term[t] = j <= p.j_last ? av_term(p, q, j) : 0.0f;
+  }
+  while (base <= p.j_last) {
+#pragma unroll
+    for (int t = 0; t < T; t++) park[t * 64 + lane] = term[t];
+    const int nb = base + B;
+#pragma unroll
+    for (int t = 0; t < T; t++) {                    // next group's loads fly during the chain
+      const int j = nb + t * 64 + lane;
+      term[t] = j <= p.j_last ? av_term(p, q, j) : 0.0f;
     }
-    term = next;
+    const int valid = p.j_last - base + 1;           // columns left, this group included
+    if (lane == 0) {
+      if (valid >= B) {
+        const float4 *v4 = reinterpret_cast<const float4 *>(park);
+#pragma unroll 8
+        for (int i = 0; i < B / 4; i++) {
+          const float4 v = v4[i];
+          acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
+        }
+      } else {
+        for (int i = 0; i < valid; i++) acc = acc + park[i];
+      }
+    }
     base = nb;
   }
   if (lane == 0) tot[q] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) av_apply(av_data, tot[0], tot[1], tot[2], cos_wt, sin_wt, dt);
+}
+
+__global__ void av_update_exact_kernel(const float *tot, float *av_data, double cos_wt, double sin_wt, float dt)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0) av_apply(av_data, tot[0], tot[1], tot[2], cos_wt, sin_wt, dt);
 }
 
 // ---------------------------------------------------------------------------
@@ -1530,9 +1551,14 @@ void av(int blocks, float *a, float *b, float *av_data, float t)
   } else {
     const AvArgs p = make_av_args(&slab, a, b);
     const float wt = g_phys.omega * t;
-    hipLaunchKernelGGL(av_exact_kernel, dim3(1), dim3(192), 0, g_stream, p, av_data,
-                       cos((double)wt), sin((double)wt), g_phys.dt);
-    rc = (int)hipGetLastError();
+    rc = ensure_workspace();
+    if (rc == 0) {
+      float *tot = reinterpret_cast<float *>(g_ws + kMaxAvBlocks * 3);   // 4 doubles kept for totals
+      hipLaunchKernelGGL(av_exact_kernel, dim3(3), dim3(64), 0, g_stream, p, tot);
+      hipLaunchKernelGGL(av_update_exact_kernel, dim3(1), dim3(64), 0, g_stream, (const float *)tot, av_data,
+                         cos((double)wt), sin((double)wt), g_phys.dt);
+      rc = (int)hipGetLastError();
+    }
   }
   if (rc > 0) HandleError(rc, __FILE__, __LINE__);
   if (rc < 0) exit(EXIT_FAILURE);
