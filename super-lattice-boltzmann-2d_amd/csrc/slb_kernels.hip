@@ -625,7 +625,14 @@ fused2_step_kernel(const Fused2Args p)
 {
   constexpr int V = 4;
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one).  Neighbouring
+  // column strips overlap by their halo lanes, so strips that are adjacent in memory are
+  // given to workgroups of the same XCD: the shared lines are then served by that XCD's L2.
+  // (Placement only changes where re-reads are served from, never what is computed.)
+  int bx = blockIdx.x;
+  const int per_xcd = gridDim.x >> 3;
+  if (bx < (per_xcd << 3)) bx = (bx & 7) * per_xcd + (bx >> 3);
+  const int wave = (bx * blockDim.x + threadIdx.x) >> 6;
   const int jj   = p.jj0 + (wave * 62 + lane - 1) * V;          // first own column (may be < 0)
   int j_hi = p.jl[0];
 #pragma unroll
@@ -1411,9 +1418,10 @@ int slb_step_fused2(const slb_step2_geom *g, const float *a0,
 
   const int block = g_block > 0 ? g_block : 256;
   if (block % 64 != 0 || block > 256) { fprintf(stderr, "slb_step_fused2: block must be 64, 128, 192 or 256\n"); return -1; }
-  // each chunk re-forms three rows of stage A above and below itself (two of B, one of C)
+  // each chunk re-forms three rows of stage A above and below itself (two of B, one of C);
+  // 32-row chunks measured fastest at n-harmonics 128, g-grid 2^20
   int n_chunk = g_n_chunk;
-  if (n_chunk <= 0) n_chunk = 64;
+  if (n_chunk <= 0) n_chunk = 32;
   if (n_chunk > s.N) n_chunk = s.N;
   s.n_chunk = n_chunk;
   switch (g_variant) {
