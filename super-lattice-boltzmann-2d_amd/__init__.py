@@ -130,6 +130,7 @@ def lib():
         L.slb_solver_halo_pack.restype = i
         L.slb_solver_halo_unpack.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
         L.slb_solver_halo_unpack.restype = i
+        L.slb_solver_av_partial.argtypes, L.slb_solver_av_partial.restype = [C.POINTER(SolverStruct), fp], i
         L.slb_solver_get_rows.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
         L.slb_solver_get_rows.restype = i
         L.slb_solver_get_window.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
@@ -255,6 +256,11 @@ class Solver:
         rc = lib().slb_solver_halo_unpack(self._p, which, side, ncols, buf_ptr)
         if rc:
             raise RuntimeError(f"slb_solver_halo_unpack -> {rc}")
+
+    def av_partial(self, sums_ptr):
+        rc = lib().slb_solver_av_partial(self._p, sums_ptr)
+        if rc:
+            raise RuntimeError(f"slb_solver_av_partial -> {rc}")
 
     def rows(self, arr, row0=0, nrows=None):
         """Rows of device array `arr` (0=a0, 1..4=a[0..3], 5..8=b[0..3]) as a numpy

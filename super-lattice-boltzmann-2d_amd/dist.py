@@ -71,6 +71,16 @@ class HipEngine:
     def double_step_finish(self):
         self.sol.double_step_finish()
 
+    def av_partial(self):
+        sums = torch.zeros(4, dtype=torch.float64, device=self.device)
+        self.sol.av_partial(sums.data_ptr())
+        return sums
+
+    def av_update(self, sums, av_data, t):
+        rc = self.slb.lib().slb_av_update(sums.data_ptr(), av_data.data_ptr(), t)
+        if rc:
+            raise RuntimeError(f"slb_av_update -> {rc}")
+
     def pack(self, which, side, ncols, buf):
         self.sol.halo_pack(which, side, ncols, buf.data_ptr())
 
@@ -206,6 +216,22 @@ class SlabRun:
         self._finish_exchange(4, pend_main)
         self._finish_exchange(5, pend_half)
         e.double_step_finish()                       # the spares become the current lattices
+
+    # -- harmonic reductions over all slabs ---------------------------------------
+    def av(self, av_data, t):
+        """The reference's av() for the lattice the last step produced: every slab sums
+        its own columns (wave64 tree, double), the three sums are added across slabs,
+        and every rank applies the same update to its copy of av_data (6 floats on
+        the device).  `t` is the loop time of the step just taken."""
+        sums = self.eng.av_partial()
+        if self.world > 1:
+            if self.cpu_staging and sums.is_cuda:
+                host = sums.cpu()
+                dist.all_reduce(host, group=self.group)
+                sums.copy_(host)
+            else:
+                dist.all_reduce(sums, group=self.group)
+        self.eng.av_update(sums, av_data, t)
 
     def close(self):
         self.eng.close()

@@ -127,6 +127,10 @@ int slb_solver_run_timed(slb_solver *s, int steps, float *ms);
 int slb_solver_halo_pack  (slb_solver *s, int which, int side, int ncols, float *buf);
 int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const float *buf);
 
+/* av() over slabs: each slab's partial sums (3 doubles, device) of its own columns of
+ * the current main lattice; add them across slabs, then slb_av_update(sums, av_data, t) */
+int slb_solver_av_partial(slb_solver *s, double *sums);
+
 /* copy rows [row0, row0+nrows) of device array `arr` (0 = a0, 1..4 = a[0..3],
  * 5..8 = b[0..3]) into dst as nrows x pitch floats */
 int slb_solver_get_rows(slb_solver *s, int arr, int row0, int nrows, float *dst);

@@ -456,6 +456,14 @@ int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const 
   return slb_halo_unpack(a, b, s->pitch, s->N + 1, col, ncols, buf);
 }
 
+/* this slab's share of the three av() sums over its own columns of the CURRENT main
+ * lattice (the one the reference passes as a/b[next] before it swaps); sums = 3
+ * doubles on the device, to be added across slabs and given to slb_av_update() */
+int slb_solver_av_partial(slb_solver *s, double *sums)
+{
+  return slb_av_partial(&s->av_slab, s->a[s->current], s->b[s->current], sums);
+}
+
 int slb_solver_get_rows(slb_solver *s, int arr, int row0, int nrows, float *dst)
 {
   const float *src = arr == 0 ? s->a0 : (arr <= 4 ? s->a[arr - 1] : s->b[arr - 5]);

@@ -47,12 +47,16 @@ def _worker(rank, world, port, outdir, mode):
         else:
             run.step()
         k += 1
+    # av() over slabs after the last step, twice (running averages)
+    av_data = torch.zeros(6, dtype=torch.float32, device="cuda")
+    run.av(av_data, 0.25)
+    run.av(av_data, 0.251)
     torch.cuda.synchronize()
     sol = run.eng.sol
     s = sol.s
     lo = s.G - 1 if rank == 0 else s.G
     hi = s.G + s.W + 2 if rank == world - 1 else s.G + s.W
-    np.savez(os.path.join(outdir, f"r{rank}.npz"), t=np.float32(s.t),
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), t=np.float32(s.t), av=av_data.cpu().numpy(),
              idx=np.array([s.current, s.next, s.current_hs, s.next_hs]),
              **{f"a{i}": sol.rows(1 + i)[:, lo:hi] for i in range(4)},
              **{f"b{i}": sol.rows(5 + i)[:, lo:hi] for i in range(4)})
@@ -76,4 +80,16 @@ def test_slabs_on_one_gpu(world, mode, tmp_path):
             exp = ref.array(w, i)
             assert got.shape == exp.shape
             assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (w, i)
+    # the slab-wise av() agrees on every rank and with the oracle's sequential sums up to
+    # the rounding noise of a float running sum
+    import ctypes as C
+    av_ref = np.zeros(6, dtype=np.float32)
+    a_cur, b_cur = ref.array("a", ref.st.current), ref.array("b", ref.st.current)
+    for t in (0.25, 0.251):
+        ob.lib().orc_av(C.byref(p), np.ascontiguousarray(a_cur), np.ascontiguousarray(b_cur), av_ref, np.float32(t))
+    for x in parts:
+        assert np.array_equal(x["av"], parts[0]["av"])
+    assert parts[0]["av"][0] == 2.0
+    scale = np.abs(av_ref[1:]).max()
+    assert np.all(np.abs(parts[0]["av"][1:] - av_ref[1:]) <= 2e-5 * scale + 1e-9)
     ref.close()
