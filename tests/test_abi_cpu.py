@@ -79,3 +79,38 @@ def test_invalid_values(solver_bin, tmp_path):
     # display modes that are out of scope are refused, not silently accepted
     r = _run(solver_bin, ["display=7"] + ARGS[1:] + ["o=stdout"], cwd=tmp_path)
     assert r.returncode == 1 and "display=7 is not available" in r.stderr
+
+
+def test_argument_errors_are_reported_without_a_launch(slb, capfd):
+    """Bad geometry, misaligned arrays, aliasing outputs and empty ranges are handled
+    on the host: -1 (or 0 for "nothing to do") comes back before any kernel launch."""
+    L = slb.lib()
+    slb.configure(N=8, M=61, E_dc=1.0, E_omega=0.1, omega=1.0, mu=5.0, alpha=1.0, B=1.0,
+                  PhiYmin=-4.0, PhiYmax=4.0)
+    ok = [0x1000 * (i + 1) for i in range(13)]             # fake, 16-byte aligned device addresses
+    f2 = (C.c_float * 2)(0.5, 0.5)
+
+    # two-sweep form
+    assert L.slb_sweep(C.byref(slb.Slab(64, 0, 0, 10)), *ok[:7], 0.5, 0.5) == -1      # j_first < 1
+    assert L.slb_sweep(C.byref(slb.Slab(64, 0, 1, 63)), *ok[:7], 0.5, 0.5) == -1      # j_last > pitch-2
+    assert L.slb_sweep(C.byref(slb.Slab(64, 0, 5, 4)), *ok[:7], 0.5, 0.5) == 0        # empty range
+    L.slb_set_tuning(2, 0, 0)
+    assert L.slb_sweep(C.byref(slb.Slab(67, 0, 1, 60)), *ok[:7], 0.5, 0.5) == -1      # 16-byte kernel, odd pitch
+    bad = list(ok[:7]); bad[3] += 4
+    assert L.slb_sweep(C.byref(slb.Slab(64, 0, 1, 60)), *bad, 0.5, 0.5) == -1         # misaligned array
+    L.slb_set_tuning(0, 0, 96)
+    assert L.slb_sweep(C.byref(slb.Slab(64, 0, 1, 60)), *ok[:7], 0.5, 0.5) == -1      # block not a multiple of 64
+    L.slb_set_tuning(0, 0, 0)
+
+    # one launch per step
+    c4 = (C.c_float * 4)(1, 1, 1, 1)
+    g = slb.StepGeom(66, 0, 1, 62, 1, 61)
+    assert L.slb_step_fused(C.byref(g), *ok[:9], C.byref(c4)) == -1                   # pitch not a multiple of 4
+    g = slb.StepGeom(64, 0, 5, 4, 5, 4)
+    assert L.slb_step_fused(C.byref(g), *ok[:9], C.byref(c4)) == 0                    # empty
+
+    # halo movers and reductions
+    assert L.slb_halo_pack(ok[0], ok[1], 64, 9, 63, 2, ok[2]) == -1                   # columns run off the row
+    assert L.slb_halo_unpack(ok[0], ok[1], 64, 0, 1, 1, ok[2]) == -1                  # no rows
+    err = capfd.readouterr().err
+    assert "bad geometry" in err and "16-byte aligned" in err and "block must be" in err
