@@ -199,6 +199,19 @@ int slb_av_update(const double *sums, float *av_data, float t);
 enum { SLB_AV_EXACT = 0, SLB_AV_TREE = 1 };
 void slb_set_av_mode(int mode);
 
+/* display=8 frame values, the inner loops of the reference's print_2d_data
+ * (src/boltzmann_solver.c:495-504) without the text formatting:
+ *   out[p*ncols + c] = max(0, sum_{n=0}^{nrows-1} a[n][m] cos(n phi_x[p]) + b[n][m] sin(n phi_x[p])),
+ *   m = col_first + c, for p = 0..nphi-1 and c = 0..ncols-1.
+ * cs (device, 16-byte aligned) holds the trigonometric factors as the host's
+ * libm gives them: cs[2*(p*nrows + n)] = cos((double)(n*phi_x[p])), the next
+ * double the sine, the product n*phi_x[p] formed in float like the reference.
+ * The running value is a float; each term is formed and added in double and
+ * rounded back after every harmonic, which reproduces the reference's value
+ * bit for bit.  a, b: device arrays [nrows][pitch]; out: device, nphi*ncols floats. */
+int slb_frame_values(const float *a, const float *b, int pitch, int nrows, int col_first, int ncols,
+                     const double *cs, int nphi, float *out);
+
 /* Stream for every launch of this library (a hipStream_t passed as void*). */
 void  slb_set_stream(void *hip_stream);
 void *slb_get_stream(void);

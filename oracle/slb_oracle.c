@@ -370,24 +370,39 @@ int orc_solver_run(orc_state *s, int display, FILE *out, FILE *log, long max_ste
   return 0;
 }
 
+/* one output value of the display=8 frame (reference: src/boltzmann_solver.c:497-502) */
+static float frame_value(const orc_params *p, const float *a, const float *b, int m, float phi_x)
+{
+  const size_t P = (size_t)p->MSIZE;
+  float value = 0;
+  for (int n = 0; n < p->N + 1; n++)
+    value += a[n * P + m] * cos(n * phi_x) + b[n * P + m] * sin(n * phi_x);
+  return value < 0 ? 0 : value;
+}
+
+/* the frame's values without the text: out[i*(M+1) + (m-1)] for phi_x[i], m = 1..M+1 */
+void orc_frame_values(const orc_params *p, const float *a, const float *b,
+                      const float *phi_x, int nphi, float *out)
+{
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < nphi; i++)
+    for (int m = 1; m < p->M + 2; m++)
+      out[(size_t)i * (p->M + 1) + (m - 1)] = frame_value(p, a, b, m, phi_x[i]);
+}
+
 /* reference: src/boltzmann_solver.c:487-507, read with the CPU row pitch M+3.
  * The norm there runs over the flat index 1..2M+1 (spills into row 1). */
 void orc_print_2d_data(const orc_params *p, FILE *out, FILE *log,
                        const float *a, const float *b, float t)
 {
-  const size_t P = (size_t)p->MSIZE;
   fprintf(out, "# t=%0.20f\n", t);
   float norm = 0;
   for (int m = 1; m < 2 * p->M + 2; m++) norm += a[m] * p->dPhi;
   norm *= 2 * ORC_PI * sqrt(p->alpha);
 
   for (float phi_x = -ORC_PI; phi_x < ORC_PI; phi_x += 0.01) {
-    for (int m = 1; m < p->M + 2; m++) {
-      float value = 0;
-      for (int n = 0; n < p->N + 1; n++)
-        value += a[n * P + m] * cos(n * phi_x) + b[n * P + m] * sin(n * phi_x);
-      fprintf(out, "%0.5f %0.5f %0.20f\n", phi_x, orc_phi_y(p, m), value < 0 ? 0 : value);
-    }
+    for (int m = 1; m < p->M + 2; m++)
+      fprintf(out, "%0.5f %0.5f %0.20f\n", phi_x, orc_phi_y(p, m), frame_value(p, a, b, m, phi_x));
   }
   fprintf(out, "# norm=%0.20f\n", norm);
   fprintf(log, "# norm=%0.20f\n", norm);

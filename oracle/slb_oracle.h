@@ -105,6 +105,11 @@ int orc_solver_run(orc_state *s, int display, FILE *out, FILE *log, long max_ste
 void orc_print_2d_data(const orc_params *p, FILE *out, FILE *log,
                        const float *a, const float *b, float t);
 
+/* The values that frame holds, without the text: out[i*(M+1) + (m-1)] for
+ * phi_x[i], i = 0..nphi-1, and columns m = 1..M+1. */
+void orc_frame_values(const orc_params *p, const float *a, const float *b,
+                      const float *phi_x, int nphi, float *out);
+
 void orc_set_threads(int n);
 int  orc_get_threads(void);
 

@@ -24,6 +24,7 @@ _INT_GLOBALS = ("host_M", "host_N", "MSIZE", "MP1", "NSIZE", "host_TMSIZE", "PAD
 # every symbol include/slb_abi.h declares
 ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "HandleError",
                  "slb_sweep", "slb_step_fused", "slb_step_fused2", "slb_step_multi", "slb_halo_pack", "slb_halo_unpack", "slb_av_partial",
+                 "slb_frame_values",
                  "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream",
                  "slb_set_tuning", "slb_version")
 ABI_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha",
@@ -131,6 +132,9 @@ def lib():
         L.slb_solver_halo_unpack.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
         L.slb_solver_halo_unpack.restype = i
         L.slb_solver_av_partial.argtypes, L.slb_solver_av_partial.restype = [C.POINTER(SolverStruct), fp], i
+        L.slb_frame_values.argtypes, L.slb_frame_values.restype = [fp, fp, i, i, i, i, fp, i, fp], i
+        L.slb_solver_frame_values.argtypes = [C.POINTER(SolverStruct), fp, i, fp]
+        L.slb_solver_frame_values.restype = i
         L.slb_solver_get_rows.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
         L.slb_solver_get_rows.restype = i
         L.slb_solver_get_window.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
@@ -261,6 +265,18 @@ class Solver:
         rc = lib().slb_solver_av_partial(self._p, sums_ptr)
         if rc:
             raise RuntimeError(f"slb_solver_av_partial -> {rc}")
+
+    def frame_values(self, phi_x):
+        """display=8 values of the current main lattice for the given phi_x values:
+        a (len(phi_x), columns) float32 array, columns = the slab's main-lattice columns."""
+        import numpy as np
+        phi_x = np.ascontiguousarray(phi_x, dtype=np.float32)
+        ms = self.s.main_slab
+        out = np.empty((len(phi_x), ms.j_last - ms.j_first + 1), dtype=np.float32)
+        rc = lib().slb_solver_frame_values(self._p, phi_x.ctypes.data, len(phi_x), out.ctypes.data)
+        if rc:
+            raise RuntimeError(f"slb_solver_frame_values -> {rc}")
+        return out
 
     def rows(self, arr, row0=0, nrows=None):
         """Rows of device array `arr` (0=a0, 1..4=a[0..3], 5..8=b[0..3]) as a numpy

@@ -1143,6 +1143,47 @@ __global__ void av_update_exact_kernel(const float *tot, float *av_data, double 
   if (threadIdx.x == 0 && blockIdx.x == 0) av_apply(av_data, tot[0], tot[1], tot[2], cos_wt, sin_wt, dt);
 }
 
+// display=8 frame: out[p][c] = max(0, sum_n a[n][m] cos(n phi_x[p]) + b[n][m] sin(n phi_x[p])),
+// m = col_first + c (reference: src/boltzmann_solver.c:495-504).  The sum keeps the
+// reference's order and precisions: a float running value, each term formed and
+// added in double, rounded back to float after every harmonic.  cs[p][n] holds
+// (cos, sin) of n*phi_x[p] as the host's libm returns them, so the device adds
+// nothing of its own to the result.  A lane owns one column and P phi_x values;
+// the table entries are the same for the whole workgroup (scalar loads).
+template <int P>
+__global__ void __launch_bounds__(256) frame_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                    int pitch, int nrows, int col_first, int ncols,
+                                                    const double2 *__restrict__ cs, int nphi,
+                                                    float *__restrict__ out)
+{
+  const int c  = blockIdx.x * 256 + threadIdx.x;
+  const int p0 = blockIdx.y * P;
+  if (c >= ncols) return;
+  const float *pa = a + col_first + c;
+  const float *pb = b + col_first + c;
+  const double2 *row[P];
+#pragma unroll
+  for (int p = 0; p < P; p++) {
+    const int pp = p0 + p < nphi ? p0 + p : nphi - 1;     // the last tile repeats a row; stores are guarded
+    row[p] = cs + (size_t)pp * nrows;
+  }
+  float v[P];
+#pragma unroll
+  for (int p = 0; p < P; p++) v[p] = 0.0f;
+  for (int n = 0; n < nrows; n++) {
+    const double ad = (double)pa[(size_t)n * pitch];
+    const double bd = (double)pb[(size_t)n * pitch];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      const double2 k = row[p][n];
+      v[p] = (float)((double)v[p] + (ad * k.x + bd * k.y));
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; p++)
+    if (p0 + p < nphi) out[(size_t)(p0 + p) * ncols + c] = v[p] < 0 ? 0.0f : v[p];
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1511,6 +1552,22 @@ int slb_halo_unpack(float *a, float *b, int pitch, int nrows, int col, int ncols
   if (nrows < 1 || ncols < 1 || col < 0 || col + ncols > pitch) return -1;
   const int n = 2 * ncols * nrows;
   hipLaunchKernelGGL(halo_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, a, b, pitch, nrows, col, ncols, buf);
+  return (int)hipGetLastError();
+}
+
+int slb_frame_values(const float *a, const float *b, int pitch, int nrows, int col_first, int ncols,
+                     const double *cs, int nphi, float *out)
+{
+  if (nrows < 1 || pitch < 1 || col_first < 0 || ncols < 0 || col_first + ncols > pitch || nphi < 0) {
+    fprintf(stderr, "slb_frame_values: bad geometry\n");
+    return -1;
+  }
+  if (ncols == 0 || nphi == 0) return 0;
+  if (!aligned16(cs)) { fprintf(stderr, "slb_frame_values: table must be 16-byte aligned\n"); return -1; }
+  constexpr int P = 8;
+  dim3 grid((ncols + 255) / 256, (nphi + P - 1) / P);
+  hipLaunchKernelGGL((frame_kernel<P>), grid, dim3(256), 0, g_stream, a, b, pitch, nrows, col_first, ncols,
+                     reinterpret_cast<const double2 *>(cs), nphi, out);
   return (int)hipGetLastError();
 }
 

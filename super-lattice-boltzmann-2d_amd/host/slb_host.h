@@ -131,6 +131,10 @@ int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const 
  * the current main lattice; add them across slabs, then slb_av_update(sums, av_data, t) */
 int slb_solver_av_partial(slb_solver *s, double *sums);
 
+/* display=8 frame values (device sums, host libm factors) of the slab's main-lattice
+ * columns for nphi values of phi_x; out = nphi x (main_slab.j_last-j_first+1) floats on the host */
+int slb_solver_frame_values(slb_solver *s, const float *phi_x, int nphi, float *out);
+
 /* copy rows [row0, row0+nrows) of device array `arr` (0 = a0, 1..4 = a[0..3],
  * 5..8 = b[0..3]) into dst as nrows x pitch floats */
 int slb_solver_get_rows(slb_solver *s, int arr, int row0, int nrows, float *dst);

@@ -75,37 +75,42 @@ static void write_display4(float norm, const float *a01, const float *b1, int pi
 
 /* display=8: f(phi_x, phi_y) = max(0, sum_n a_n cos(n phi_x) + b_n sin(n phi_x))
  * on 629 phi_x values x columns 1..M+1 (reference: src/boltzmann_solver.c:487-507).
- * cos(n*phi_x) and sin(n*phi_x) do not depend on the column, so they are formed
- * once per phi_x; each output value goes through the same operations as in
- * the reference loop.  The closing norm uses the unpadded (CPU) row pitch for
- * its flat-index sum, so it does not depend on how device rows are padded. */
-static void write_frame8(FILE *f, const float *a, const float *b, int pitch, float t)
+ * The sums run on the device, a batch of phi_x values at a time
+ * (slb_solver_frame_values); this function keeps the reference's phi_x
+ * sequence (a float advanced by 0.01 in double) and its text format.  The
+ * closing norm uses the unpadded (CPU) row pitch for its flat-index sum, so it
+ * does not depend on how device rows are padded; a01 = rows 0 and 1 of a. */
+static int write_frame8(FILE *f, slb_solver *s, const float *a01, int pitch, float t)
 {
   const int cpu_pitch = host_M + 3;
   fprintf(f, "# t=%0.20f\n", t);
   float norm = 0;
   for (int m = 1; m < 2 * host_M + 2; m++) {
     const int r = m >= cpu_pitch ? 1 : 0;
-    norm += a[(size_t)r * pitch + (m - r * cpu_pitch)] * host_dPhi;
+    norm += a01[(size_t)r * pitch + (m - r * cpu_pitch)] * host_dPhi;
   }
   norm *= 2 * SLB_PI * sqrt(host_alpha);
 
-  double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)(host_N + 1));
-  for (float phi_x = -SLB_PI; phi_x < SLB_PI; phi_x += 0.01) {
-    for (int n = 0; n < host_N + 1; n++) {
-      cs[2 * n]     = cos(n * phi_x);
-      cs[2 * n + 1] = sin(n * phi_x);
-    }
-    for (int m = 1; m < host_M + 2; m++) {
-      float value = 0;
-      for (int n = 0; n < host_N + 1; n++)
-        value += a[(size_t)n * pitch + m] * cs[2 * n] + b[(size_t)n * pitch + m] * cs[2 * n + 1];
-      fprintf(f, "%0.5f %0.5f %0.20f\n", phi_x, PhiYmin + host_dPhi * (m - 1), value < 0 ? 0 : value);
-    }
+  const int ncols = host_M + 1;
+  int batch = (int)((64u << 20) / (unsigned)ncols);        /* at most 64 Mi values (256 MiB) per batch */
+  batch = batch < 8 ? 8 : (batch > 640 ? 640 : batch / 8 * 8);
+  float *phis = (float *)malloc(sizeof(float) * batch);
+  float *vals = (float *)malloc(sizeof(float) * (size_t)batch * ncols);
+  if (!phis || !vals) { fprintf(stderr, "ERROR: out of host memory for the frame\n"); return -1; }
+  float phi_x = -SLB_PI;
+  while (phi_x < SLB_PI) {
+    int np = 0;
+    for (; np < batch && phi_x < SLB_PI; phi_x += 0.01) phis[np++] = phi_x;
+    if (slb_solver_frame_values(s, phis, np, vals) != 0) return -1;
+    for (int p = 0; p < np; p++)
+      for (int m = 1; m < host_M + 2; m++)
+        fprintf(f, "%0.5f %0.5f %0.20f\n", phis[p], PhiYmin + host_dPhi * (m - 1),
+                vals[(size_t)p * ncols + (m - 1)]);
   }
-  free(cs);
+  free(phis); free(vals);
   fprintf(f, "# norm=%0.20f\n", norm);
   printf("# norm=%0.20f\n", norm);
+  return 0;
 }
 
 int slb_main(int argc, char **argv)
@@ -213,16 +218,12 @@ int slb_main(int argc, char **argv)
     const float norm = slb_host_norm(a_rows, host_M, host_dPhi, host_alpha);
 
     if (display == 8) {
-      const size_t cells = (size_t)(host_N + 1) * pitch;
-      float *fa = (float *)malloc(sizeof(float) * cells), *fb = (float *)malloc(sizeof(float) * cells);
-      slb_solver_get_rows(s, 1 + s->current, 0, host_N + 1, fa);
-      slb_solver_get_rows(s, 5 + s->current, 0, host_N + 1, fb);
       FILE *f = fopen("frame.data", "w");
       if (!f) { perror("ERROR"); return EXIT_FAILURE; }
       printf("\nWriting frame %s\n", "frame.data");
-      write_frame8(f, fa, fb, pitch, t);
+      const int rc = write_frame8(f, s, a_rows, pitch, t);
       fclose(f);
-      free(fa); free(fb);
+      if (rc != 0) return EXIT_FAILURE;
       break;
     }
     if (display == 4) write_display4(norm, a_rows, b_rows, pitch, av6, T);

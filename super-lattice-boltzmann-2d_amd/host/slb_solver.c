@@ -464,6 +464,43 @@ int slb_solver_av_partial(slb_solver *s, double *sums)
   return slb_av_partial(&s->av_slab, s->a[s->current], s->b[s->current], sums);
 }
 
+/* display=8 frame values of this slab's main-lattice columns (main_slab.j_first..j_last;
+ * 1..M+1 for a single slab) for nphi values of phi_x: out (host) receives
+ * nphi x ncols floats, row p = phi_x[p].  The cos/sin factors come from the host's
+ * libm with the argument n*phi_x formed in float, as in the reference
+ * (src/boltzmann_solver.c:495-504); the sums run on the device. */
+int slb_solver_frame_values(slb_solver *s, const float *phi_x, int nphi, float *out)
+{
+  const int nrows = s->N + 1;
+  const int col_first = s->main_slab.j_first;
+  const int ncols = s->main_slab.j_last - s->main_slab.j_first + 1;
+  if (nphi < 1 || ncols < 1) return -1;
+  const size_t tab_bytes = sizeof(double) * 2 * (size_t)nphi * nrows;
+  const size_t out_bytes = sizeof(float) * (size_t)nphi * ncols;
+  double *tab = (double *)malloc(tab_bytes);
+  if (!tab) return -1;
+  for (int p = 0; p < nphi; p++)
+    for (int n = 0; n < nrows; n++) {
+      tab[2 * ((size_t)p * nrows + n)]     = cos(n * phi_x[p]);
+      tab[2 * ((size_t)p * nrows + n) + 1] = sin(n * phi_x[p]);
+    }
+  double *d_tab = NULL;
+  float  *d_out = NULL;
+  HIP_OK(hipMalloc((void **)&d_tab, tab_bytes));
+  HIP_OK(hipMalloc((void **)&d_out, out_bytes));
+  HIP_OK(hipMemcpy(d_tab, tab, tab_bytes, hipMemcpyHostToDevice));
+  free(tab);
+  const int rc = slb_frame_values(s->a[s->current], s->b[s->current], s->pitch, nrows, col_first, ncols,
+                                  d_tab, nphi, d_out);
+  if (rc == 0) {
+    HIP_OK(hipStreamSynchronize((hipStream_t)slb_get_stream()));
+    HIP_OK(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
+  }
+  HIP_OK(hipFree(d_tab));
+  HIP_OK(hipFree(d_out));
+  return rc;
+}
+
 int slb_solver_get_rows(slb_solver *s, int arr, int row0, int nrows, float *dst)
 {
   const float *src = arr == 0 ? s->a0 : (arr <= 4 ? s->a[arr - 1] : s->b[arr - 5]);

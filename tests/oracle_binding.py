@@ -55,6 +55,7 @@ def lib():
         L.orc_state_free.argtypes, L.orc_state_free.restype = [C.POINTER(State)], None
         L.orc_state_step.argtypes, L.orc_state_step.restype = [C.POINTER(State)], None
         L.orc_set_threads.argtypes, L.orc_set_threads.restype = [C.c_int], None
+        L.orc_frame_values.argtypes, L.orc_frame_values.restype = [PP, fp, fp, fp, C.c_int, fp], None
         _lib = L
     return _lib
 
@@ -94,6 +95,23 @@ class OracleState:
 
     def close(self):
         lib().orc_state_free(C.byref(self.st))
+
+
+def frame_phi_x():
+    """The reference's phi_x sequence for display=8: a float advanced by 0.01 in double
+    (reference: src/boltzmann_solver.c:495)."""
+    out, x = [], np.float32(-3.14159265358979323846)
+    while x < 3.14159265358979323846:
+        out.append(x)
+        x = np.float32(np.float64(x) + 0.01)
+    return np.array(out, dtype=np.float32)
+
+
+def frame_values(p, a, b, phi_x):
+    phi_x = np.ascontiguousarray(phi_x, dtype=np.float32)
+    out = np.empty((len(phi_x), p.M + 1), dtype=np.float32)
+    lib().orc_frame_values(C.byref(p), a, b, phi_x, len(phi_x), out)
+    return out
 
 
 def run_cli(args, threads=8, timeout=600, cwd=None):

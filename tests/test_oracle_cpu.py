@@ -94,3 +94,28 @@ def test_display77_trace_shape(oracle, tmp_path):
     v_dr = [float(r[4]) for r in rec]
     assert all(b > a for a, b in zip(v_dr, v_dr[1:])) and 0.03 < v_dr[0] < 0.08
     assert all(abs(float(r[6]) - 1) < 2e-4 for r in rec)
+
+
+def test_frame_values_are_what_the_frame_file_holds(oracle, tmp_path):
+    """orc_frame_values (what the device kernel is compared with) and the display=8
+    text writer share one loop: the file's third column is those values, printed."""
+    args = ["display=8", "omega=100", "B=0.5", "n-harmonics=8", "g-grid=61", "t-max=0.01",
+            "E_dc=1", "E_omega=0.1", "mu=5", "alpha=1", "PhiYmin=-4", "PhiYmax=4", "dt=0.001"]
+    oracle.run_cli(args + ["o=out.txt"], cwd=tmp_path)
+    lines = [l for l in (tmp_path / "frame.data").read_text().splitlines() if not l.startswith("#")]
+    p = oracle.make_params(N=8, M=61, B=0.5, omega=100.0, t_start=0.01)
+    orc = oracle.OracleState(p)
+    try:
+        while orc.st.t < orc.st.t_max:
+            orc.step(1)
+        phi = oracle.frame_phi_x()
+        cur = orc.st.current
+        vals = oracle.frame_values(p, orc.array("a", cur), orc.array("b", cur), phi)
+        assert len(lines) == vals.size == 629 * 62
+        want = ["%0.5f" % x for x in phi]
+        for k in (0, 1, 61, 62, 300 * 62 + 17, 628 * 62 + 61):
+            px, py, v = lines[k].split()
+            assert px == want[k // 62] and v == "%0.20f" % vals[k // 62, k % 62]
+        assert all(l.split()[2] == "%0.20f" % v for l, v in zip(lines, vals.ravel()))
+    finally:
+        orc.close()
