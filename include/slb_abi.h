@@ -179,6 +179,17 @@ int slb_step_multi(const slb_multi_geom *geom, const float *a0, const float *con
 int slb_halo_pack  (const float *a, const float *b, int pitch, int nrows, int col, int ncols, float *buf);
 int slb_halo_unpack(float *a, float *b, int pitch, int nrows, int col, int ncols, const float *buf);
 
+/* The same for up to four (array pair, column run, buffer) segments in ONE launch:
+ * what a slab sends to (or receives from) both neighbours after a step, main and
+ * half-step lattice together.  Each segment's buffer is laid out as above. */
+typedef struct slb_halo_seg {
+  float *a, *b;     /* the two arrays, [nrows][pitch] */
+  int    col, ncols;
+  float *buf;       /* 2*ncols*nrows floats */
+} slb_halo_seg;
+int slb_halo_pack_segs  (const slb_halo_seg *segs, int nsegs, int pitch, int nrows);
+int slb_halo_unpack_segs(const slb_halo_seg *segs, int nsegs, int pitch, int nrows);
+
 /* First stage of av(): the three sums over local columns j_first..j_last
  * (b[1][m]*dPhi, a[0][m]*phi_y(m)*dPhi, a[1][m]*dPhi), terms formed in float as
  * the reference does, accumulated in double by a wave64 shuffle tree.

@@ -23,7 +23,7 @@ _INT_GLOBALS = ("host_M", "host_N", "MSIZE", "MP1", "NSIZE", "host_TMSIZE", "PAD
 
 # every symbol include/slb_abi.h declares
 ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "HandleError",
-                 "slb_sweep", "slb_step_fused", "slb_step_fused2", "slb_step_multi", "slb_halo_pack", "slb_halo_unpack", "slb_av_partial",
+                 "slb_sweep", "slb_step_fused", "slb_step_fused2", "slb_step_multi", "slb_halo_pack", "slb_halo_unpack", "slb_halo_pack_segs", "slb_halo_unpack_segs", "slb_av_partial",
                  "slb_frame_values",
                  "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream",
                  "slb_set_tuning", "slb_version")
@@ -42,6 +42,11 @@ class Slab(C.Structure):
 class StepGeom(C.Structure):
     _fields_ = [("pitch", C.c_int), ("m_offset", C.c_int), ("j1_first", C.c_int), ("j1_last", C.c_int),
                 ("j2_first", C.c_int), ("j2_last", C.c_int)]
+
+
+class HaloSeg(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("col", C.c_int), ("ncols", C.c_int),
+                ("buf", C.c_void_p)]
 
 
 class SolverStruct(C.Structure):
@@ -132,6 +137,14 @@ def lib():
         L.slb_solver_halo_unpack.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
         L.slb_solver_halo_unpack.restype = i
         L.slb_solver_av_partial.argtypes, L.slb_solver_av_partial.restype = [C.POINTER(SolverStruct), fp], i
+        L.slb_halo_pack_segs.argtypes = [C.POINTER(HaloSeg), i, i, i]
+        L.slb_halo_pack_segs.restype = i
+        L.slb_halo_unpack_segs.argtypes = [C.POINTER(HaloSeg), i, i, i]
+        L.slb_halo_unpack_segs.restype = i
+        L.slb_solver_halo_pack_double.argtypes = [C.POINTER(SolverStruct), fp, fp]
+        L.slb_solver_halo_pack_double.restype = i
+        L.slb_solver_halo_unpack_double.argtypes = [C.POINTER(SolverStruct), fp, fp]
+        L.slb_solver_halo_unpack_double.restype = i
         L.slb_frame_values.argtypes, L.slb_frame_values.restype = [fp, fp, i, i, i, i, fp, i, fp], i
         L.slb_solver_frame_values.argtypes = [C.POINTER(SolverStruct), fp, i, fp]
         L.slb_solver_frame_values.restype = i
@@ -260,6 +273,18 @@ class Solver:
         rc = lib().slb_solver_halo_unpack(self._p, which, side, ncols, buf_ptr)
         if rc:
             raise RuntimeError(f"slb_solver_halo_unpack -> {rc}")
+
+    def halo_pack_double(self, left_ptr, right_ptr):
+        """Both new lattices' edge columns after a double step's edge ranges, one launch;
+        a pointer of None means no neighbour on that side."""
+        rc = lib().slb_solver_halo_pack_double(self._p, left_ptr, right_ptr)
+        if rc:
+            raise RuntimeError(f"slb_solver_halo_pack_double -> {rc}")
+
+    def halo_unpack_double(self, left_ptr, right_ptr):
+        rc = lib().slb_solver_halo_unpack_double(self._p, left_ptr, right_ptr)
+        if rc:
+            raise RuntimeError(f"slb_solver_halo_unpack_double -> {rc}")
 
     def av_partial(self, sums_ptr):
         rc = lib().slb_solver_av_partial(self._p, sums_ptr)

@@ -1008,6 +1008,27 @@ __global__ void halo_unpack_kernel(float *a, float *b, int pitch, int nrows, int
   dst[(size_t)r * pitch + col + c] = buf[i];
 }
 
+// several (array pair, column run, buffer) segments in one launch: segment k covers
+// elements start[k] .. start[k+1]-1 of the launch, laid out in its buffer like
+// halo_pack_kernel's
+struct HaloSegs {
+  float *a[4], *b[4], *buf[4];
+  int col[4], ncols[4], start[5];
+  int nsegs, pitch, nrows;
+};
+template <bool PACK>
+__global__ void halo_segs_kernel(const HaloSegs h)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= h.start[h.nsegs]) return;
+  int k = 0;
+  while (k + 1 < h.nsegs && i >= h.start[k + 1]) k++;
+  const int e = i - h.start[k];
+  const int r = e % h.nrows, qc = e / h.nrows, c = qc % h.ncols[k];
+  float *cell = (qc < h.ncols[k] ? h.a[k] : h.b[k]) + (size_t)r * h.pitch + h.col[k] + c;
+  if (PACK) h.buf[k][e] = *cell; else *cell = h.buf[k][e];
+}
+
 // ---------------------------------------------------------------------------
 // reductions (reference: src/boltzmann_c_solver.c:413-437)
 // ---------------------------------------------------------------------------
@@ -1405,7 +1426,13 @@ int slb_step_fused(const slb_step_geom *g,
   // large shape tried (waves of different chunks run out of phase and keep HBM busy), and
   // narrow lattices need the extra workgroups anyway.
   int n_chunk = g_n_chunk;
-  if (n_chunk <= 0) n_chunk = 16;
+  if (n_chunk <= 0) {
+    // a launch only a few columns wide (a slab's edge range) is a handful of waves whose
+    // run time is the length of their row loop: short chunks finish it sooner
+    const int lo = s.j1_first < s.j2_first ? s.j1_first : s.j2_first;
+    const int hi = s.j1_last > s.j2_last ? s.j1_last : s.j2_last;
+    n_chunk = hi - lo < 4 * 248 ? 4 : 16;
+  }
   if (n_chunk > s.N) n_chunk = s.N;
   s.n_chunk = n_chunk;
   switch (g_variant) {
@@ -1462,7 +1489,13 @@ int slb_step_fused2(const slb_step2_geom *g, const float *a0,
   // each chunk re-forms three rows of stage A above and below itself (two of B, one of C);
   // 32-row chunks measured fastest at n-harmonics 128, g-grid 2^20
   int n_chunk = g_n_chunk;
-  if (n_chunk <= 0) n_chunk = 32;
+  if (n_chunk <= 0) {
+    // a launch only a few columns wide (a slab's edge range) is a handful of waves whose
+    // run time is the length of their row loop: short chunks finish it sooner
+    int lo = s.jf[0], hi = s.jl[0];
+    for (int q = 1; q < 4; q++) { lo = s.jf[q] < lo ? s.jf[q] : lo; hi = s.jl[q] > hi ? s.jl[q] : hi; }
+    n_chunk = hi - lo < 4 * 248 ? 4 : 32;
+  }
   if (n_chunk > s.N) n_chunk = s.N;
   s.n_chunk = n_chunk;
   switch (g_variant) {
@@ -1553,6 +1586,34 @@ int slb_halo_unpack(float *a, float *b, int pitch, int nrows, int col, int ncols
   const int n = 2 * ncols * nrows;
   hipLaunchKernelGGL(halo_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, a, b, pitch, nrows, col, ncols, buf);
   return (int)hipGetLastError();
+}
+
+static int halo_segs(const slb_halo_seg *segs, int nsegs, int pitch, int nrows, bool pack)
+{
+  if (!segs || nsegs < 1 || nsegs > 4 || nrows < 1 || pitch < 1) return -1;
+  HaloSegs h;
+  h.nsegs = nsegs; h.pitch = pitch; h.nrows = nrows; h.start[0] = 0;
+  for (int k = 0; k < nsegs; k++) {
+    if (segs[k].ncols < 1 || segs[k].col < 0 || segs[k].col + segs[k].ncols > pitch ||
+        !segs[k].a || !segs[k].b || !segs[k].buf) return -1;
+    h.a[k] = segs[k].a; h.b[k] = segs[k].b; h.buf[k] = segs[k].buf;
+    h.col[k] = segs[k].col; h.ncols[k] = segs[k].ncols;
+    h.start[k + 1] = h.start[k] + 2 * segs[k].ncols * nrows;
+  }
+  const int n = h.start[nsegs];
+  if (pack) hipLaunchKernelGGL(halo_segs_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, g_stream, h);
+  else      hipLaunchKernelGGL(halo_segs_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, g_stream, h);
+  return (int)hipGetLastError();
+}
+
+int slb_halo_pack_segs(const slb_halo_seg *segs, int nsegs, int pitch, int nrows)
+{
+  return halo_segs(segs, nsegs, pitch, nrows, true);
+}
+
+int slb_halo_unpack_segs(const slb_halo_seg *segs, int nsegs, int pitch, int nrows)
+{
+  return halo_segs(segs, nsegs, pitch, nrows, false);
 }
 
 int slb_frame_values(const float *a, const float *b, int pitch, int nrows, int col_first, int ncols,

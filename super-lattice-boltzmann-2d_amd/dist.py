@@ -84,6 +84,14 @@ class HipEngine:
     def pack(self, which, side, ncols, buf):
         self.sol.halo_pack(which, side, ncols, buf.data_ptr())
 
+    def pack_double(self, left, right):
+        self.sol.halo_pack_double(None if left is None else left.data_ptr(),
+                                  None if right is None else right.data_ptr())
+
+    def unpack_double(self, left, right):
+        self.sol.halo_unpack_double(None if left is None else left.data_ptr(),
+                                    None if right is None else right.data_ptr())
+
     def unpack(self, which, side, ncols, buf):
         self.sol.halo_unpack(which, side, ncols, buf.data_ptr())
 
@@ -109,35 +117,64 @@ class SlabRun:
         # [ncols][side] send / receive buffers
         self.send = {n: [self.eng.new_buffer(n), self.eng.new_buffer(n)] for n in (1, 2, 3, 4)}
         self.recv = {n: [self.eng.new_buffer(n), self.eng.new_buffer(n)] for n in (1, 2, 3, 4)}
+        # a double step's message per side: 3 main-lattice columns, then 4 half-step columns
+        self.send2 = [self.eng.new_buffer(7), self.eng.new_buffer(7)]
+        self.recv2 = [self.eng.new_buffer(7), self.eng.new_buffer(7)]
         self.cpu_staging = dist.is_initialized() and dist.get_backend(group) == "gloo"
 
-    # -- halo exchange of lattice `which` (see slb_solver_halo_pack) ----------
-    def _start_exchange(self, which, ncols):
+    # -- transport: one message per neighbour, all of them in one batch ---------
+    def _post(self, send, recv):
+        """Send send[side] to / receive recv[side] from each neighbour; returns what
+        _complete() needs.  The messages travel while later launches run."""
         ops, staged = [], []
         for side, peer in ((0, self.left), (1, self.right)):
             if peer is None:
                 continue
-            s_dev, r_dev = self.send[ncols][side], self.recv[ncols][side]
-            self.eng.pack(which, side, ncols, s_dev)
-            if self.cpu_staging and s_dev.is_cuda:
-                s_buf, r_buf = s_dev.cpu(), torch.empty_like(r_dev, device="cpu")
-                staged.append((side, r_buf))
-            else:
-                s_buf, r_buf = s_dev, r_dev
+            s_buf, r_buf = send[side], recv[side]
+            if self.cpu_staging and s_buf.is_cuda:
+                s_buf, r_buf = s_buf.cpu(), torch.empty_like(r_buf, device="cpu")
+                staged.append((recv[side], r_buf))
             ops.append(dist.P2POp(dist.isend, s_buf, peer, group=self.group))
             ops.append(dist.P2POp(dist.irecv, r_buf, peer, group=self.group))
         reqs = dist.batch_isend_irecv(ops) if ops else []
-        return reqs, staged, ncols
+        return reqs, staged
 
-    def _finish_exchange(self, which, pending):
-        reqs, staged, ncols = pending
+    @staticmethod
+    def _complete(posted):
+        reqs, staged = posted
         for r in reqs:
             r.wait()
-        for side, r_buf in staged:
-            self.recv[ncols][side].copy_(r_buf)
+        for r_dev, r_buf in staged:
+            r_dev.copy_(r_buf)
+
+    # -- halo exchange of lattice `which` (see slb_solver_halo_pack) ----------
+    def _start_exchange(self, which, ncols):
+        for side, peer in ((0, self.left), (1, self.right)):
+            if peer is not None:
+                self.eng.pack(which, side, ncols, self.send[ncols][side])
+        return self._post(self.send[ncols], self.recv[ncols]), ncols
+
+    def _finish_exchange(self, which, pending):
+        posted, ncols = pending
+        self._complete(posted)
         for side, peer in ((0, self.left), (1, self.right)):
             if peer is not None:
                 self.eng.unpack(which, side, ncols, self.recv[ncols][side])
+
+    # -- both lattices of a double step in one message per side -----------------
+    def _double_halo(self, bufs, pack):
+        e = self.eng
+        left = bufs[0] if self.left is not None else None
+        right = bufs[1] if self.right is not None else None
+        if hasattr(e, "pack_double"):                 # one launch for everything
+            (e.pack_double if pack else e.unpack_double)(left, right)
+            return
+        split = 2 * 3 * (e.N + 1)
+        for side, buf in ((0, left), (1, right)):
+            if buf is not None:
+                move = e.pack if pack else e.unpack
+                move(4, side, 3, buf[:split])         # spare main lattice
+                move(5, side, 4, buf[split:])         # spare half-step lattice
 
     def exchange(self, which, ncols):
         self._finish_exchange(which, self._start_exchange(which, ncols))
@@ -209,12 +246,12 @@ class SlabRun:
         if self.right is not None:
             e.double_step_range(last_owned - 3, last_owned, c)
             hi = last_owned - 4
-        # the edge columns of both new lattices sit in the spare arrays (4 = main, 5 = half-step)
-        pend_main = self._start_exchange(4, 3)
-        pend_half = self._start_exchange(5, 4)
+        # the edge columns of both new lattices sit in the spare arrays
+        self._double_halo(self.send2, pack=True)
+        posted = self._post(self.send2, self.recv2)
         e.double_step_range(lo, hi, c)
-        self._finish_exchange(4, pend_main)
-        self._finish_exchange(5, pend_half)
+        self._complete(posted)
+        self._double_halo(self.recv2, pack=False)
         e.double_step_finish()                       # the spares become the current lattices
 
     # -- harmonic reductions over all slabs ---------------------------------------

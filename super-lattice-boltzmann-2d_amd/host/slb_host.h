@@ -131,6 +131,12 @@ int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const 
  * the current main lattice; add them across slabs, then slb_av_update(sums, av_data, t) */
 int slb_solver_av_partial(slb_solver *s, double *sums);
 
+/* halo traffic of a double step in one launch per direction: per neighbour a buffer of
+ * 2*7*(N+1) floats (3 main-lattice columns, then 4 half-step columns, taken from / put
+ * into the spare arrays); NULL for a side without a neighbour */
+int slb_solver_halo_pack_double  (slb_solver *s, float *buf_left, float *buf_right);
+int slb_solver_halo_unpack_double(slb_solver *s, float *buf_left, float *buf_right);
+
 /* display=8 frame values (device sums, host libm factors) of the slab's main-lattice
  * columns for nphi values of phi_x; out = nphi x (main_slab.j_last-j_first+1) floats on the host */
 int slb_solver_frame_values(slb_solver *s, const float *phi_x, int nphi, float *out);

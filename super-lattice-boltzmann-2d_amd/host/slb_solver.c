@@ -456,6 +456,44 @@ int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const 
   return slb_halo_unpack(a, b, s->pitch, s->N + 1, col, ncols, buf);
 }
 
+/* After a double step's edge ranges: the outermost owned columns of the new main lattice
+ * (3 columns) and of the new half-step lattice (4 columns), both still in the spare arrays,
+ * gathered for each neighbour in one launch.  A side's buffer (NULL = no neighbour there)
+ * holds 2*3*(N+1) floats of the main lattice followed by 2*4*(N+1) of the half-step one. */
+static int halo_double(slb_solver *s, float *buf_left, float *buf_right, int pack)
+{
+  const int nrows = s->N + 1;
+  if (!s->spare_a || s->G < 4) return -1;
+  slb_halo_seg seg[4];
+  int k = 0;
+  for (int side = 0; side < 2; side++) {
+    float *buf = side == 0 ? buf_left : buf_right;
+    if (!buf) continue;
+    for (int lat = 0; lat < 2; lat++) {
+      const int ncols = lat == 0 ? 3 : 4;
+      seg[k].a = lat == 0 ? s->spare_a : s->spare_ah;
+      seg[k].b = lat == 0 ? s->spare_b : s->spare_bh;
+      seg[k].ncols = ncols;
+      if (pack) seg[k].col = side == 0 ? s->G : s->G + s->W - ncols;      /* outermost owned columns */
+      else      seg[k].col = side == 0 ? s->G - ncols : s->G + s->W;      /* the ghost columns next to them */
+      seg[k].buf = buf + (lat == 0 ? 0 : 2 * 3 * nrows);
+      k++;
+    }
+  }
+  if (k == 0) return 0;
+  return pack ? slb_halo_pack_segs(seg, k, s->pitch, nrows) : slb_halo_unpack_segs(seg, k, s->pitch, nrows);
+}
+
+int slb_solver_halo_pack_double(slb_solver *s, float *buf_left, float *buf_right)
+{
+  return halo_double(s, buf_left, buf_right, 1);
+}
+
+int slb_solver_halo_unpack_double(slb_solver *s, float *buf_left, float *buf_right)
+{
+  return halo_double(s, buf_left, buf_right, 0);
+}
+
 /* this slab's share of the three av() sums over its own columns of the CURRENT main
  * lattice (the one the reference passes as a/b[next] before it swaps); sums = 3
  * doubles on the device, to be added across slabs and given to slb_av_update() */
