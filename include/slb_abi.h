@@ -201,13 +201,18 @@ int slb_av_partial(const slb_slab *slab, const float *a, const float *b, double 
 int slb_av_update(const double *sums, float *av_data, float t);
 
 /* How av() forms its three sums:
- *   SLB_AV_EXACT (default) -- one wave per sum adds the terms one after the
- *       other in float, in the reference's order: bit-identical to the
- *       reference CPU av();
+ *   SLB_AV_EXACT (default) -- the terms are added in float in the reference's
+ *       order, bit-identical to the reference CPU av(), but by a whole
+ *       workgroup per sum: inside one binade of the running sum every addition
+ *       rounds to one fixed grid, so 1024 terms at a time become an integer
+ *       prefix sum; ties, binade changes and special values take a real float
+ *       addition (see slb_seq_sum);
+ *   SLB_AV_CHAIN -- the same bits from one lane per sum adding term after term
+ *       (a chain of M dependent additions; kept as a cross-check);
  *   SLB_AV_TREE -- slb_av_partial + slb_av_update: wave64 shuffle tree in
  *       double; differs from the CPU's sequential float sum by that sum's own
  *       rounding noise (about 1e-6 relative at M = 2^20). */
-enum { SLB_AV_EXACT = 0, SLB_AV_TREE = 1 };
+enum { SLB_AV_EXACT = 0, SLB_AV_TREE = 1, SLB_AV_CHAIN = 2 };
 void slb_set_av_mode(int mode);
 
 /* display=8 frame values, the inner loops of the reference's print_2d_data
@@ -222,6 +227,15 @@ void slb_set_av_mode(int mode);
  * bit for bit.  a, b: device arrays [nrows][pitch]; out: device, nphi*ncols floats. */
 int slb_frame_values(const float *a, const float *b, int pitch, int nrows, int col_first, int ncols,
                      const double *cs, int nphi, float *out);
+
+/* out[0] = the float the loop `acc = 0; for (i = 0; i < n; i++) acc = acc + x[i];`
+ * leaves in acc (IEEE single, round to nearest even, denormals kept), bit for
+ * bit, for any contents of x (device, n floats) -- evaluated by one workgroup
+ * in parallel, the way SLB_AV_EXACT forms the sums of av(). */
+int slb_seq_sum(const float *x, int n, float *out);
+/* The same, and how it went: stats[0] = parallel passes taken, stats[1] = runs of
+ * terms that one thread added one by one (device, 2 ints; may be NULL). */
+int slb_seq_sum_stats(const float *x, int n, float *out, int *stats);
 
 /* Stream for every launch of this library (a hipStream_t passed as void*). */
 void  slb_set_stream(void *hip_stream);

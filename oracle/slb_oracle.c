@@ -370,6 +370,15 @@ int orc_solver_run(orc_state *s, int display, FILE *out, FILE *log, long max_ste
   return 0;
 }
 
+/* A float running sum in index order: the shape of every sum in av() and in the
+ * display reductions (reference: src/boltzmann_c_solver.c:417-423). */
+float orc_seq_sum(const float *x, long n)
+{
+  float acc = 0;
+  for (long i = 0; i < n; i++) acc = acc + x[i];
+  return acc;
+}
+
 /* one output value of the display=8 frame (reference: src/boltzmann_solver.c:497-502) */
 static float frame_value(const orc_params *p, const float *a, const float *b, int m, float phi_x)
 {

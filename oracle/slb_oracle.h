@@ -110,6 +110,9 @@ void orc_print_2d_data(const orc_params *p, FILE *out, FILE *log,
 void orc_frame_values(const orc_params *p, const float *a, const float *b,
                       const float *phi_x, int nphi, float *out);
 
+/* acc = 0; for (i) acc = acc + x[i]; in float */
+float orc_seq_sum(const float *x, long n);
+
 void orc_set_threads(int n);
 int  orc_get_threads(void);
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time av() in both modes at a given g-grid (HIP events via torch on the null stream)."""
+"""Time av() in its three modes at a given g-grid (HIP events via torch on the null stream)."""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,7 +13,7 @@ for M in (4096, 262144, 1 << 20):
     L = slb.lib()
     sol = slb.Solver(); sol.tiptoe(); sol.step()
     s = sol.s
-    for mode, name in ((slb.SLB_AV_EXACT, "exact"), (slb.SLB_AV_TREE, "tree")):
+    for mode, name in ((slb.SLB_AV_EXACT, "exact"), (slb.SLB_AV_CHAIN, "chain"), (slb.SLB_AV_TREE, "tree")):
         L.slb_set_av_mode(mode)
         L.av(0, s.a[s.current], s.b[s.current], s.av_data, 0.1)
         torch.cuda.synchronize()

@@ -24,7 +24,7 @@ _INT_GLOBALS = ("host_M", "host_N", "MSIZE", "MP1", "NSIZE", "host_TMSIZE", "PAD
 # every symbol include/slb_abi.h declares
 ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "HandleError",
                  "slb_sweep", "slb_step_fused", "slb_step_fused2", "slb_step_multi", "slb_halo_pack", "slb_halo_unpack", "slb_halo_pack_segs", "slb_halo_unpack_segs", "slb_av_partial",
-                 "slb_frame_values",
+                 "slb_frame_values", "slb_seq_sum", "slb_seq_sum_stats",
                  "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream",
                  "slb_set_tuning", "slb_version")
 ABI_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha",
@@ -32,7 +32,7 @@ ABI_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha
                "host_bdt", "host_nu_tilde", "host_nu2", "host_nu",
                "host_M", "host_N", "MSIZE", "MP1", "NSIZE", "host_TMSIZE", "PADDED_MSIZE")
 
-SLB_AV_EXACT, SLB_AV_TREE = 0, 1
+SLB_AV_EXACT, SLB_AV_TREE, SLB_AV_CHAIN = 0, 1, 2
 
 
 class Slab(C.Structure):
@@ -95,6 +95,8 @@ def lib():
         L.slb_av_update.argtypes = [fp, fp, f]
         L.slb_av_update.restype = i
         L.slb_set_av_mode.argtypes, L.slb_set_av_mode.restype = [i], None
+        L.slb_seq_sum.argtypes, L.slb_seq_sum.restype = [fp, i, fp], i
+        L.slb_seq_sum_stats.argtypes, L.slb_seq_sum_stats.restype = [fp, i, fp, fp], i
         L.slb_set_stream.argtypes, L.slb_set_stream.restype = [vp], None
         L.slb_get_stream.argtypes, L.slb_get_stream.restype = [], vp
         L.slb_set_tuning.argtypes, L.slb_set_tuning.restype = [i, i, i], None

@@ -1159,6 +1159,220 @@ __global__ void __launch_bounds__(64) av_exact_kernel(const AvArgs p, float *tot
   if (lane == 0) tot[q] = acc;
 }
 
+// ---------------------------------------------------------------------------
+// A float sum in index order, evaluated in parallel, with the bits of the
+// sequential loop `for (i) acc = acc + x[i]`.
+//
+// While the running sum stays inside one binade, |acc| in [2^e, 2^(e+1)), every
+// addition rounds to the same grid of spacing u = 2^(e-23): with acc = A*u (A an
+// integer) and h = x/u, fl(acc + x) = (A + rint(h))*u as long as h is not exactly
+// halfway between two integers and the exact sum stays inside the binade.  Integer
+// addition is associative, so a workgroup takes a chunk of terms at once: a few
+// consecutive terms per thread, r = rint(h), a prefix sum over the workgroup, and a
+// check of every prefix against the binade.  The first term that is a tie, leaves the binade, is too large
+// or not finite is added by a real float addition instead (any term can be; the
+// test is conservative), after which the exponent is read again and the rest of the
+// chunk is redone.  When such a pass gets only a few terms further, one thread adds
+// the next few hundred terms one by one, so the worst case costs little more than
+// the plain loop.
+// ---------------------------------------------------------------------------
+constexpr int kScanBurst = 256;                 // terms one thread adds after a pass that got nowhere
+
+// W waves per workgroup, T consecutive terms per thread: a chunk is 64*W*T terms
+template <int W, int T>
+struct ScanShared {
+  int   wave_total[W];
+  int   first_bad[W];
+  int   prev_sum[W];
+  int   last_sum;
+  float acc_out;
+  __attribute__((aligned(16))) float park[64 * W * T];
+};
+
+__device__ __forceinline__ float grid_value(int S, int biased_exp)
+{
+  // S*2^(e-23) for 2^23 <= |S| < 2^24: sign, the accumulator's exponent field, S's low 23 bits
+  const unsigned sign = S < 0 ? 0x80000000u : 0u;
+  const unsigned mag  = (unsigned)(S < 0 ? -S : S);
+  return __uint_as_float(sign | ((unsigned)biased_exp << 23) | (mag & 0x7fffffu));
+}
+
+// inclusive prefix sum over the 64 lanes of a wave: shifts inside rows of 16 lanes, then
+// the last lane of a row broadcast to the rows after it
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+  return v;
+}
+
+template <int W, int T, class F>
+__device__ float seq_sum_block(F term, int n, ScanShared<W, T> &sh, int *stats = nullptr)
+{
+  constexpr int kScanChunk = 64 * W * T;
+  // |rint(h)| < 2^18 for every term of a chunk keeps all prefix sums inside an int
+  static_assert((long long)kScanChunk << 18 <= 1ll << 30, "prefix sums must fit an int");
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int e0 = tid * T;                                  // my first term's index in the chunk
+  int n_passes = 0, n_bursts = 0, burst = kScanBurst;
+  float acc = 0.0f;
+  float x[T], x_next[T];
+#pragma unroll
+  for (int t = 0; t < T; t++) x_next[t] = e0 + t < n ? term(e0 + t) : 0.0f;
+  for (int base = 0; base < n; base += kScanChunk) {
+    const int count = n - base < kScanChunk ? n - base : kScanChunk;
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      x[t] = x_next[t];
+      sh.park[e0 + t] = x[t];
+      const int jn = base + kScanChunk + e0 + t;           // the next chunk's loads fly during the scans
+      x_next[t] = jn < n ? term(jn) : 0.0f;
+    }
+    int pos = 0;
+    while (pos < count) {
+      n_passes++;
+      const unsigned ab = __float_as_uint(acc);
+      const int  be = (int)((ab >> 23) & 0xffu);
+      const bool normal = be != 0 && be != 0xff;            // else zero, denormal, inf or nan: no grid
+      // which of my terms are still to be added: bits lo..hi-1
+      const int lo = pos - e0 < 0 ? 0 : (pos - e0 > T ? T : pos - e0);
+      const int hi = count - e0 < 0 ? 0 : (count - e0 > T ? T : count - e0);
+      const unsigned mine = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+      unsigned badmask = 0;
+      int ps[T];                                            // inclusive prefix of rint(h) over my terms
+      int A0 = 0;
+      if (normal) {
+        const int m = (int)((ab & 0x7fffffu) | 0x800000u);
+        A0 = (ab >> 31) ? -m : m;
+        // h = x / 2^(e-23) with e = be - 127: a power-of-two scaling, exact in float unless
+        // it overflows (caught as "too large") or underflows (then rint(h) = 0 either way)
+        const int up = 150 - be;
+        int run = 0;
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+          const float h  = __builtin_ldexpf(x[t], up);
+          const float rr = __builtin_rintf(h);
+          const bool big = !(__builtin_fabsf(h) < 262144.0f);          // also nan, inf: goes the slow way
+          const bool tie = __builtin_fabsf(h - rr) == 0.5f;            // rounding would depend on the sum's parity
+          badmask |= (big || tie) ? 1u << t : 0u;
+          run += (((mine >> t) & 1u) && !big) ? (int)rr : 0;
+          ps[t] = run;
+        }
+      } else {
+        badmask = ~0u;
+#pragma unroll
+        for (int t = 0; t < T; t++) ps[t] = 0;
+      }
+      const int s = wave_inclusive_scan(ps[T - 1]);
+      if (lane == 63) sh.wave_total[w] = s;
+      __syncthreads();
+      int before = A0 + s - ps[T - 1];
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+        const int v = sh.wave_total[k];
+        before += k < w ? v : 0;
+      }
+      // the sum after each of my terms, in grid units; inside the binade means 2^23 < |S| < 2^24
+      if (normal) {
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+          const int S = before + ps[t];
+          const unsigned mag = (unsigned)(S < 0 ? -S : S);
+          badmask |= (mag - 0x800001u >= 0x7fffffu) ? 1u << t : 0u;
+        }
+      }
+      badmask &= mine;
+      const int t_bad = badmask ? __builtin_ctz(badmask) : T;
+      const unsigned long long vote = __ballot(badmask != 0);
+      const int first = vote ? (int)__ffsll((long long)vote) - 1 : 64;
+      if (lane == 0) sh.first_bad[w] = 0x7fffffff;
+      if (lane == first) {
+        int prev = before;                                  // the sum before my first bad term
+#pragma unroll
+        for (int t = 1; t < T; t++) prev = t == t_bad ? before + ps[t - 1] : prev;
+        sh.first_bad[w] = e0 + t_bad;
+        sh.prev_sum[w]  = prev;
+      }
+      if (e0 <= count - 1 && count - 1 < e0 + T) {
+        int last = 0;
+#pragma unroll
+        for (int t = 0; t < T; t++) last = e0 + t == count - 1 ? before + ps[t] : last;
+        sh.last_sum = last;
+      }
+      __syncthreads();
+      int jb = 0x7fffffff, pv = 0;
+#pragma unroll
+      for (int k = W - 1; k >= 0; k--) {
+        const int f = sh.first_bad[k], q = sh.prev_sum[k];
+        if (f != 0x7fffffff) { jb = f; pv = q; }
+      }
+      if (jb == 0x7fffffff) {
+        acc = grid_value(sh.last_sum, be);
+        pos = count;
+      } else {
+        const float prev = normal ? grid_value(pv, be) : acc;
+        acc = prev + sh.park[jb];                           // the real thing for this one term
+        const int advanced = jb + 1 - pos;
+        pos = jb + 1;
+        if (advanced >= kScanBurst / 2) burst = kScanBurst;
+        else if (pos < count) {
+          // the scan did not pay for itself (the sum is changing binade every few terms,
+          // or ties and specials are frequent): one thread adds the next terms one by one,
+          // twice as many after every scan in a row that got nowhere
+          const int stop = pos + burst < count ? pos + burst : count;
+          if (tid == 0) {
+            float a = acc;
+            int i = pos;
+            for (; i < stop && (i & 3); i++) a = a + sh.park[i];
+            const float4 *v4 = reinterpret_cast<const float4 *>(sh.park);
+#pragma unroll 8
+            for (; i + 4 <= stop; i += 4) {
+              const float4 v = v4[i >> 2];
+              a = a + v.x; a = a + v.y; a = a + v.z; a = a + v.w;
+            }
+            for (; i < stop; i++) a = a + sh.park[i];
+            sh.acc_out = a;
+          }
+          __syncthreads();
+          acc = sh.acc_out;
+          pos = stop;
+          burst = burst < kScanChunk ? burst * 2 : kScanChunk;
+          n_bursts++;
+        }
+      }
+      // no barrier at the end of a pass: what the next pass writes before its first barrier
+      // (wave_total) was last read before this pass's second barrier; everything else is
+      // written after the next pass's first barrier, and acc_out after the one above
+    }
+    __syncthreads();                                        // park[] is rewritten next
+  }
+  if (stats && tid == 0) { stats[0] = n_passes; stats[1] = n_bursts; }
+  return acc;
+}
+
+// exact mode, parallel form: workgroup q forms sum q
+constexpr int kAvScanWaves = 8, kAvScanPerLane = 8;     // fastest of the shapes tried at 2^20 columns
+__global__ void __launch_bounds__(64 * kAvScanWaves) av_exact_scan_kernel(const AvArgs p, float *tot)
+{
+  __shared__ ScanShared<kAvScanWaves, kAvScanPerLane> sh;
+  const int q = blockIdx.x;
+  const float acc = seq_sum_block<kAvScanWaves, kAvScanPerLane>(
+      [&](int i) { return av_term(p, q, p.j_first + i); }, p.j_last - p.j_first + 1, sh);
+  if (threadIdx.x == 0) tot[q] = acc;
+}
+
+template <int W, int T>
+__global__ void __launch_bounds__(64 * W) seq_sum_kernel(const float *x, int n, float *out, int *stats)
+{
+  __shared__ ScanShared<W, T> sh;
+  const float acc = seq_sum_block<W, T>([&](int i) { return x[i]; }, n, sh, stats);
+  if (threadIdx.x == 0) out[0] = acc;
+}
+
 __global__ void av_update_exact_kernel(const float *tot, float *av_data, double cos_wt, double sin_wt, float dt)
 {
   if (threadIdx.x == 0 && blockIdx.x == 0) av_apply(av_data, tot[0], tot[1], tot[2], cos_wt, sin_wt, dt);
@@ -1329,7 +1543,7 @@ void load_data(void)
 
 void slb_set_stream(void *s)           { g_stream = (hipStream_t)s; }
 void *slb_get_stream(void)             { return (void *)g_stream; }
-void slb_set_av_mode(int mode)         { g_av_mode = (mode == SLB_AV_TREE) ? SLB_AV_TREE : SLB_AV_EXACT; }
+void slb_set_av_mode(int mode)         { g_av_mode = (mode == SLB_AV_TREE || mode == SLB_AV_CHAIN) ? mode : SLB_AV_EXACT; }
 void slb_set_tuning(int v, int nc, int b) { g_variant = v; g_n_chunk = nc; g_block = b; }
 const char *slb_version(void)          { return "slb2d-gfx950 0.1"; }
 
@@ -1632,6 +1846,27 @@ int slb_frame_values(const float *a, const float *b, int pitch, int nrows, int c
   return (int)hipGetLastError();
 }
 
+int slb_seq_sum_stats(const float *x, int n, float *out, int *stats)
+{
+  if (n < 0 || (n > 0 && !x) || !out) return -1;
+  // slb_set_tuning variants 41..47 select other workgroup shapes (waves x terms per thread)
+#define SLB_SEQ(W, T) hipLaunchKernelGGL((seq_sum_kernel<W, T>), dim3(1), dim3(64 * W), 0, g_stream, x, n, out, stats)
+  switch (g_variant) {
+    case 41: SLB_SEQ(4, 4); break;
+    case 42: SLB_SEQ(8, 4); break;
+    case 43: SLB_SEQ(16, 2); break;
+    case 44: SLB_SEQ(4, 8); break;
+    case 45: SLB_SEQ(16, 4); break;
+    case 46: SLB_SEQ(1, 16); break;
+    case 47: SLB_SEQ(2, 8); break;
+    default: SLB_SEQ(kAvScanWaves, kAvScanPerLane); break;
+  }
+#undef SLB_SEQ
+  return (int)hipGetLastError();
+}
+
+int slb_seq_sum(const float *x, int n, float *out) { return slb_seq_sum_stats(x, n, out, nullptr); }
+
 static AvArgs make_av_args(const slb_slab *slab, const float *a, const float *b)
 {
   AvArgs p;
@@ -1680,7 +1915,10 @@ void av(int blocks, float *a, float *b, float *av_data, float t)
     rc = ensure_workspace();
     if (rc == 0) {
       float *tot = reinterpret_cast<float *>(g_ws + kMaxAvBlocks * 3);   // 4 doubles kept for totals
-      hipLaunchKernelGGL(av_exact_kernel, dim3(3), dim3(64), 0, g_stream, p, tot);
+      // both give the CPU's bits; below a few ten thousand columns the one-lane chain is
+      // done before the parallel form has paid for its passes
+      if (g_av_mode == SLB_AV_CHAIN || p.j_last - p.j_first < 32768) hipLaunchKernelGGL(av_exact_kernel, dim3(3), dim3(64), 0, g_stream, p, tot);
+      else hipLaunchKernelGGL(av_exact_scan_kernel, dim3(3), dim3(64 * kAvScanWaves), 0, g_stream, p, tot);
       hipLaunchKernelGGL(av_update_exact_kernel, dim3(1), dim3(64), 0, g_stream, (const float *)tot, av_data,
                          cos((double)wt), sin((double)wt), g_phys.dt);
       rc = (int)hipGetLastError();

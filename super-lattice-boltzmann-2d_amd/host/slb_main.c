@@ -143,10 +143,11 @@ int slb_main(int argc, char **argv)
   const int one_launch   = form != NULL && strcmp(form, "fused") == 0;
 
   /* SLB_AV=tree: wave64 tree reduction for av() (about 10 us) instead of the default
-   * exact-order sums (bit-identical to the CPU solver, but a chain of M dependent
-   * additions: about 7 ms at g-grid 2^20) */
+   * exact-order sums (bit-identical to the CPU solver; about 1 ms at g-grid 2^20);
+   * SLB_AV=chain: the exact sums by one lane adding term after term (cross-check) */
   const char *avm = getenv("SLB_AV");
-  slb_set_av_mode(avm != NULL && strcmp(avm, "tree") == 0 ? SLB_AV_TREE : SLB_AV_EXACT);
+  slb_set_av_mode(avm != NULL && strcmp(avm, "tree") == 0 ? SLB_AV_TREE :
+                  avm != NULL && strcmp(avm, "chain") == 0 ? SLB_AV_CHAIN : SLB_AV_EXACT);
 
   int   progress = 0;
   float frame_time = 0;

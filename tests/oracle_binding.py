@@ -55,6 +55,7 @@ def lib():
         L.orc_state_free.argtypes, L.orc_state_free.restype = [C.POINTER(State)], None
         L.orc_state_step.argtypes, L.orc_state_step.restype = [C.POINTER(State)], None
         L.orc_set_threads.argtypes, L.orc_set_threads.restype = [C.c_int], None
+        L.orc_seq_sum.argtypes, L.orc_seq_sum.restype = [fp, C.c_long], C.c_float
         L.orc_frame_values.argtypes, L.orc_frame_values.restype = [PP, fp, fp, fp, C.c_int, fp], None
         _lib = L
     return _lib
@@ -95,6 +96,11 @@ class OracleState:
 
     def close(self):
         lib().orc_state_free(C.byref(self.st))
+
+
+def seq_sum(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return np.float32(lib().orc_seq_sum(x, len(x)))
 
 
 def frame_phi_x():
