@@ -224,7 +224,9 @@ void slb_set_av_mode(int mode);
  * double the sine, the product n*phi_x[p] formed in float like the reference.
  * The running value is a float; each term is formed and added in double and
  * rounded back after every harmonic, which reproduces the reference's value
- * bit for bit.  a, b: device arrays [nrows][pitch]; out: device, nphi*ncols floats. */
+ * bit for bit.  a, b: device arrays [nrows][pitch]; out: device, nphi*ncols floats.
+ * b == NULL leaves the sine terms out: the sum display=3 forms over the
+ * equilibrium coefficients a0 (reference: src/boltzmann_solver.c:322). */
 int slb_frame_values(const float *a, const float *b, int pitch, int nrows, int col_first, int ncols,
                      const double *cs, int nphi, float *out);
 

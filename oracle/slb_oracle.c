@@ -324,12 +324,73 @@ static void orc_print_display4(orc_state *s, int display, FILE *out, FILE *log, 
           mmx, av_data[1], av_data[2], av_data[3], av_data[5]);
 }
 
+static float orc_frame_start = 0;      /* frame-start= of the command line (display=7) */
+void orc_set_frame_start(float t) { orc_frame_start = t; }
+
+static float frame_value(const orc_params *p, const float *a, const float *b, int m, float phi_x);
+
+/* display=9: add this period's frame to the running strobe image and write it
+ * (reference: src/boltzmann_solver.c:459-484; the norm there is the trapezoid-looking
+ * sum over columns 1..M) */
+static void orc_print_2d_strobe(const orc_params *p, FILE *out, FILE *log, float *strobe,
+                                const float *a, const float *b, float t)
+{
+  float norm = 0;
+  float dphi_over_2 = p->dPhi / 2.0;
+  for (int m = 1; m < p->M + 1; m++) norm += (a[m] + a[m]) * dphi_over_2;
+  norm *= 2 * ORC_PI * sqrt(p->alpha);
+  size_t i = 0;
+  for (float phi_x = -ORC_PI; phi_x < ORC_PI; phi_x += 0.01) {
+    for (int m = 1; m < p->M + 2; m++) {
+      strobe[i] = strobe[i] + frame_value(p, a, b, m, phi_x);
+      fprintf(out, "%0.5f %0.5f %0.20f\n", phi_x, orc_phi_y(p, m), strobe[i]);
+      i++;
+    }
+  }
+  fprintf(out, "# norm=%0.20f\n", norm);
+  fprintf(out, "# t=%0.20f\n", t);
+  fprintf(log, "# norm=%0.20f\n", norm);
+}
+
+/* display=3: the distribution next to the equilibrium one, columns 1..M-1
+ * (reference: src/boltzmann_c_solver.c:219-234) */
+static void orc_print_display3(const orc_params *p, FILE *out, FILE *log, float norm,
+                               const float *a0, const float *a, const float *b)
+{
+  const size_t P = (size_t)p->MSIZE;
+  for (float phi_x = -ORC_PI; phi_x < ORC_PI; phi_x += 0.01) {
+    for (int m = 1; m < p->M; m++) {
+      float value = 0, value0 = 0;
+      for (int n = 0; n < p->N + 1; n++) {
+        value  += a[n * P + m] * cos(n * phi_x) + b[n * P + m] * sin(n * phi_x);
+        value0 += a0[n * P + m] * cos(n * phi_x);
+      }
+      fprintf(out, "%0.5f %0.5f %0.20f %0.20f\n", phi_x, orc_phi_y(p, m),
+              value < 0 ? 0 : value, value0 < 0 ? 0 : value0);
+    }
+  }
+  fprintf(out, "# norm=%0.20f\n", norm);
+  fprintf(log, "# norm=%0.20f\n", norm);
+}
+
 /* reference: src/boltzmann_c_solver.c:157-268 (one pass of the outer loop, no
- * stdin re-parameterisation). */
+ * stdin re-parameterisation).  display=7 and display=9 follow the CUDA host
+ * (src/boltzmann_solver.c:255-287), the only place that has the strobe and the
+ * frame-start test; its frame writer is the one that stays inside the arrays. */
 int orc_solver_run(orc_state *s, int display, FILE *out, FILE *log, long max_steps)
 {
   const orc_params *p = &s->p;
-  int progress = 0;
+  int progress = 0, frame_number = 1;
+  float last_tT_reminder = 0;
+  float *strobe = NULL;
+  char name[64];
+  if (display == 9) {
+    s->t_max = p->t_start + 101 * s->T;
+    size_t size = 0;
+    for (float phi_x = -ORC_PI; phi_x < ORC_PI; phi_x += 0.01) size += (size_t)p->M + 1;
+    strobe = (float *)calloc(size, sizeof(float));
+    if (!strobe) return -1;
+  }
   fprintf(log, "# t_max = %0.20f\n", s->t_max);
 
   for (s->t = s->t0; s->t < s->t_max; s->t += p->dt) {
@@ -347,6 +408,30 @@ int orc_solver_run(orc_state *s, int display, FILE *out, FILE *log, long max_ste
 
     orc_swap(s);
 
+    if (display == 9 && s->t >= p->t_start) {
+      float tT = s->t / s->T;
+      float tT_reminder = tT - ((int)tT);
+      if (tT_reminder < last_tT_reminder) {
+        sprintf(name, "strobe%08d.data", frame_number++);
+        FILE *f = fopen(name, "w");
+        if (!f) return -1;
+        fprintf(log, "\nWriting strobe %s\n", name);
+        orc_print_2d_strobe(p, f, log, strobe, s->a[s->current], s->b[s->current], s->t);
+        fclose(f);
+        s->frame_time = 0;
+      }
+      last_tT_reminder = tT_reminder;
+    }
+    if (display == 7 && s->frame_time >= 0.01 && s->t > orc_frame_start) {
+      sprintf(name, "frame%08d.data", frame_number++);
+      FILE *f = fopen(name, "w");
+      if (!f) return -1;
+      fprintf(log, "\nWriting frame %s\n", name);
+      orc_print_2d_data(p, f, log, s->a[s->current], s->b[s->current], s->t);
+      fclose(f);
+      s->frame_time = 0;
+    }
+
     if (out != stdout && display != 7) {
       if (++progress == 300) {
         fprintf(log, "\rt=%0.9f %0.2f%%", s->t, s->t / s->t_max * 100);
@@ -358,7 +443,9 @@ int orc_solver_run(orc_state *s, int display, FILE *out, FILE *log, long max_ste
     s->steps_done++;
   }
 
+  free(strobe);
   float norm = orc_eval_norm(p, s->a[s->current]);
+  if (display == 3) orc_print_display3(p, out, log, norm, s->a0, s->a[s->current], s->b[s->current]);
   if (display == 4) orc_print_display4(s, display, out, log, norm);
   if (display == 8) {
     FILE *f = fopen("frame.data", "w");

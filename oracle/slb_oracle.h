@@ -97,8 +97,13 @@ void orc_state_step(orc_state *s);
 /* The reference main(): time loop + display=4 / display=77 output
  * (reference: src/boltzmann_c_solver.c:83-287, 298-331).  `out` receives what
  * the reference writes to its o= file, `log` what it writes to stdout.
- * max_steps<0 means "run to t_max". */
+ * display=3 dumps the final distribution to `out`; display=7 writes
+ * frameNNNNNNNN.data and display=9 strobeNNNNNNNN.data into the working directory
+ * (reference: src/boltzmann_solver.c:255-287).  max_steps<0 means "run to t_max". */
 int orc_solver_run(orc_state *s, int display, FILE *out, FILE *log, long max_steps);
+
+/* frame-start= for display=7 (frames are written only for t > frame_start) */
+void orc_set_frame_start(float t);
 
 /* display=8 frame writer (reference: src/boltzmann_solver.c:487-507, the only
  * definition that takes t; the CPU solver emits nothing for display=8). */

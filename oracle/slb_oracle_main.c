@@ -3,8 +3,8 @@
  *
  * TEST INFRASTRUCTURE ONLY.  Takes the reference's name=value arguments
  * (reference: src/boltzmann_cli.c:105-122) and writes what the reference CPU
- * solver writes for display=4 / display=77 (and a display=8 frame.data built
- * from the oracle fields).  Extra argument: threads=K (OpenMP threads).
+ * solver writes for display=3 / 4 / 77, and the frame files of display=7 / 8 / 9
+ * as the reference's CUDA host writes them, built from the oracle fields.  Extra argument: threads=K (OpenMP threads).
  */
 #include "slb_oracle.h"
 
@@ -42,6 +42,7 @@ int main(int argc, char **argv)
     else if (!strcmp(k, "o"))           o         = v;
     else if (!strcmp(k, "threads"))     threads   = atoi(v);
     else if (!strcmp(k, "max-steps"))   max_steps = atol(v);
+    else if (!strcmp(k, "frame-start")) orc_set_frame_start(strtod(v, NULL));
   }
   if (display < -900 || p.N < -900 || p.E_dc < -900 || p.E_omega < -900 || p.omega < -900 ||
       p.mu < -900 || p.alpha < -900 || p.PhiYmin < -900 || p.PhiYmax < -900 || p.B < -900 ||

@@ -148,7 +148,7 @@ def lib():
         L.slb_solver_halo_unpack_double.argtypes = [C.POINTER(SolverStruct), fp, fp]
         L.slb_solver_halo_unpack_double.restype = i
         L.slb_frame_values.argtypes, L.slb_frame_values.restype = [fp, fp, i, i, i, i, fp, i, fp], i
-        L.slb_solver_frame_values.argtypes = [C.POINTER(SolverStruct), fp, i, fp]
+        L.slb_solver_frame_values.argtypes = [C.POINTER(SolverStruct), i, fp, i, fp]
         L.slb_solver_frame_values.restype = i
         L.slb_solver_get_rows.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
         L.slb_solver_get_rows.restype = i
@@ -293,14 +293,15 @@ class Solver:
         if rc:
             raise RuntimeError(f"slb_solver_av_partial -> {rc}")
 
-    def frame_values(self, phi_x):
-        """display=8 values of the current main lattice for the given phi_x values:
-        a (len(phi_x), columns) float32 array, columns = the slab's main-lattice columns."""
+    def frame_values(self, phi_x, source=0):
+        """display=8 values of the current main lattice (source=0) or of the equilibrium
+        coefficients a0 (source=1) for the given phi_x values: a (len(phi_x), columns)
+        float32 array, columns = the slab's main-lattice columns."""
         import numpy as np
         phi_x = np.ascontiguousarray(phi_x, dtype=np.float32)
         ms = self.s.main_slab
         out = np.empty((len(phi_x), ms.j_last - ms.j_first + 1), dtype=np.float32)
-        rc = lib().slb_solver_frame_values(self._p, phi_x.ctypes.data, len(phi_x), out.ctypes.data)
+        rc = lib().slb_solver_frame_values(self._p, source, phi_x.ctypes.data, len(phi_x), out.ctypes.data)
         if rc:
             raise RuntimeError(f"slb_solver_frame_values -> {rc}")
         return out

@@ -1385,7 +1385,9 @@ __global__ void av_update_exact_kernel(const float *tot, float *av_data, double 
 // (cos, sin) of n*phi_x[p] as the host's libm returns them, so the device adds
 // nothing of its own to the result.  A lane owns one column and P phi_x values;
 // the table entries are the same for the whole workgroup (scalar loads).
-template <int P>
+// SINES = false leaves the b terms out: the equilibrium distribution's sum over a0
+// (reference: src/boltzmann_solver.c:322).
+template <int P, bool SINES>
 __global__ void __launch_bounds__(256) frame_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                     int pitch, int nrows, int col_first, int ncols,
                                                     const double2 *__restrict__ cs, int nphi,
@@ -1395,7 +1397,7 @@ __global__ void __launch_bounds__(256) frame_kernel(const float *__restrict__ a,
   const int p0 = blockIdx.y * P;
   if (c >= ncols) return;
   const float *pa = a + col_first + c;
-  const float *pb = b + col_first + c;
+  const float *pb = SINES ? b + col_first + c : nullptr;
   const double2 *row[P];
 #pragma unroll
   for (int p = 0; p < P; p++) {
@@ -1407,11 +1409,12 @@ __global__ void __launch_bounds__(256) frame_kernel(const float *__restrict__ a,
   for (int p = 0; p < P; p++) v[p] = 0.0f;
   for (int n = 0; n < nrows; n++) {
     const double ad = (double)pa[(size_t)n * pitch];
-    const double bd = (double)pb[(size_t)n * pitch];
+    const double bd = SINES ? (double)pb[(size_t)n * pitch] : 0.0;
 #pragma unroll
     for (int p = 0; p < P; p++) {
       const double2 k = row[p][n];
-      v[p] = (float)((double)v[p] + (ad * k.x + bd * k.y));
+      if (SINES) v[p] = (float)((double)v[p] + (ad * k.x + bd * k.y));
+      else       v[p] = (float)((double)v[p] + ad * k.x);
     }
   }
 #pragma unroll
@@ -1841,8 +1844,10 @@ int slb_frame_values(const float *a, const float *b, int pitch, int nrows, int c
   if (!aligned16(cs)) { fprintf(stderr, "slb_frame_values: table must be 16-byte aligned\n"); return -1; }
   constexpr int P = 8;
   dim3 grid((ncols + 255) / 256, (nphi + P - 1) / P);
-  hipLaunchKernelGGL((frame_kernel<P>), grid, dim3(256), 0, g_stream, a, b, pitch, nrows, col_first, ncols,
-                     reinterpret_cast<const double2 *>(cs), nphi, out);
+  if (b) hipLaunchKernelGGL((frame_kernel<P, true>), grid, dim3(256), 0, g_stream, a, b, pitch, nrows, col_first,
+                            ncols, reinterpret_cast<const double2 *>(cs), nphi, out);
+  else   hipLaunchKernelGGL((frame_kernel<P, false>), grid, dim3(256), 0, g_stream, a, b, pitch, nrows, col_first,
+                            ncols, reinterpret_cast<const double2 *>(cs), nphi, out);
   return (int)hipGetLastError();
 }
 

@@ -137,9 +137,10 @@ int slb_solver_av_partial(slb_solver *s, double *sums);
 int slb_solver_halo_pack_double  (slb_solver *s, float *buf_left, float *buf_right);
 int slb_solver_halo_unpack_double(slb_solver *s, float *buf_left, float *buf_right);
 
-/* display=8 frame values (device sums, host libm factors) of the slab's main-lattice
- * columns for nphi values of phi_x; out = nphi x (main_slab.j_last-j_first+1) floats on the host */
-int slb_solver_frame_values(slb_solver *s, const float *phi_x, int nphi, float *out);
+/* frame values (device sums, host libm factors) of the slab's main-lattice columns for
+ * nphi values of phi_x; out = nphi x (main_slab.j_last-j_first+1) floats on the host.
+ * source 0: current lattice; 1: equilibrium a0 (cosine terms only) */
+int slb_solver_frame_values(slb_solver *s, int source, const float *phi_x, int nphi, float *out);
 
 /* copy rows [row0, row0+nrows) of device array `arr` (0 = a0, 1..4 = a[0..3],
  * 5..8 = b[0..3]) into dst as nrows x pitch floats */

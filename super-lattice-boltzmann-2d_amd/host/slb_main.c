@@ -1,7 +1,7 @@
 /*
  * slb_main.c -- the boltzmann_solver program: same command line and the same
- * display=4 / display=8 / display=77 outputs as the reference, driving the
- * gfx950 kernels through the boundary in include/slb_abi.h.
+ * display=3 / 4 / 7 / 8 / 9 / 77 outputs as the reference, driving the gfx950
+ * kernels through the boundary in include/slb_abi.h.
  *
  * Control flow follows the reference host (reference: src/boltzmann_solver.c:74-401);
  * where the reference's CUDA host and its CPU solver disagree (column ranges,
@@ -73,13 +73,69 @@ static void write_display4(float norm, const float *a01, const float *b1, int pi
           s3[2], av6[1], av6[2], av6[3], av6[5]);
 }
 
-/* display=8: f(phi_x, phi_y) = max(0, sum_n a_n cos(n phi_x) + b_n sin(n phi_x))
- * on 629 phi_x values x columns 1..M+1 (reference: src/boltzmann_solver.c:487-507).
- * The sums run on the device, a batch of phi_x values at a time
- * (slb_solver_frame_values); this function keeps the reference's phi_x
- * sequence (a float advanced by 0.01 in double) and its text format.  The
- * closing norm uses the unpadded (CPU) row pitch for its flat-index sum, so it
- * does not depend on how device rows are padded; a01 = rows 0 and 1 of a. */
+/* f(phi_x, phi_y) = max(0, sum_n a_n cos(n phi_x) + b_n sin(n phi_x)) on the reference's
+ * 629 phi_x values (a float advanced by 0.01 in double, src/boltzmann_solver.c:495) x
+ * grid columns: the sums run on the device a batch of phi_x values at a time
+ * (slb_solver_frame_values); `line` gets every batch to print.  with_a0 also
+ * forms the equilibrium distribution's values (display=3). */
+typedef void (*frame_line_fn)(FILE *f, void *ctx, float phi_x, int p_global, const float *vals,
+                              const float *vals0, int ncols);
+
+static int for_each_frame_row(slb_solver *s, FILE *f, int with_a0, frame_line_fn line, void *ctx)
+{
+  const int ncols = host_M + 1;
+  int batch = (int)((64u << 20) / (unsigned)ncols);        /* at most 64 Mi values (256 MiB) per batch */
+  batch = batch < 8 ? 8 : (batch > 640 ? 640 : batch / 8 * 8);
+  float *phis  = (float *)malloc(sizeof(float) * batch);
+  float *vals  = (float *)malloc(sizeof(float) * (size_t)batch * ncols);
+  float *vals0 = with_a0 ? (float *)malloc(sizeof(float) * (size_t)batch * ncols) : NULL;
+  if (!phis || !vals || (with_a0 && !vals0)) {
+    fprintf(stderr, "ERROR: out of host memory for the frame\n");
+    return -1;
+  }
+  float phi_x = -SLB_PI;
+  int done = 0;
+  while (phi_x < SLB_PI) {
+    int np = 0;
+    for (; np < batch && phi_x < SLB_PI; phi_x += 0.01) phis[np++] = phi_x;
+    if (slb_solver_frame_values(s, 0, phis, np, vals) != 0) return -1;
+    if (with_a0 && slb_solver_frame_values(s, 1, phis, np, vals0) != 0) return -1;
+    for (int p = 0; p < np; p++)
+      line(f, ctx, phis[p], done + p, vals + (size_t)p * ncols, with_a0 ? vals0 + (size_t)p * ncols : NULL, ncols);
+    done += np;
+  }
+  free(phis); free(vals); free(vals0);
+  return 0;
+}
+
+static void line_frame(FILE *f, void *ctx, float phi_x, int p, const float *vals, const float *vals0, int ncols)
+{
+  (void)ctx; (void)p; (void)vals0;
+  for (int m = 1; m < host_M + 2; m++)
+    fprintf(f, "%0.5f %0.5f %0.20f\n", phi_x, PhiYmin + host_dPhi * (m - 1), vals[m - 1]);
+  (void)ncols;
+}
+
+static void line_strobe(FILE *f, void *ctx, float phi_x, int p, const float *vals, const float *vals0, int ncols)
+{
+  float *strobe = (float *)ctx + (size_t)p * ncols;
+  (void)vals0;
+  for (int m = 1; m < host_M + 2; m++) {
+    strobe[m - 1] = strobe[m - 1] + vals[m - 1];
+    fprintf(f, "%0.5f %0.5f %0.20f\n", phi_x, PhiYmin + host_dPhi * (m - 1), strobe[m - 1]);
+  }
+}
+
+static void line_display3(FILE *f, void *ctx, float phi_x, int p, const float *vals, const float *vals0, int ncols)
+{
+  (void)ctx; (void)p; (void)ncols;
+  for (int m = 1; m < host_M; m++)
+    fprintf(f, "%0.5f %0.5f %0.20f %0.20f\n", phi_x, PhiYmin + host_dPhi * (m - 1), vals[m - 1], vals0[m - 1]);
+}
+
+/* display=7 / display=8 frame file (reference: src/boltzmann_solver.c:487-507).  The
+ * closing norm uses the unpadded (CPU) row pitch for its flat-index sum, so it does
+ * not depend on how device rows are padded; a01 = rows 0 and 1 of a. */
 static int write_frame8(FILE *f, slb_solver *s, const float *a01, int pitch, float t)
 {
   const int cpu_pitch = host_M + 3;
@@ -90,40 +146,54 @@ static int write_frame8(FILE *f, slb_solver *s, const float *a01, int pitch, flo
     norm += a01[(size_t)r * pitch + (m - r * cpu_pitch)] * host_dPhi;
   }
   norm *= 2 * SLB_PI * sqrt(host_alpha);
-
-  const int ncols = host_M + 1;
-  int batch = (int)((64u << 20) / (unsigned)ncols);        /* at most 64 Mi values (256 MiB) per batch */
-  batch = batch < 8 ? 8 : (batch > 640 ? 640 : batch / 8 * 8);
-  float *phis = (float *)malloc(sizeof(float) * batch);
-  float *vals = (float *)malloc(sizeof(float) * (size_t)batch * ncols);
-  if (!phis || !vals) { fprintf(stderr, "ERROR: out of host memory for the frame\n"); return -1; }
-  float phi_x = -SLB_PI;
-  while (phi_x < SLB_PI) {
-    int np = 0;
-    for (; np < batch && phi_x < SLB_PI; phi_x += 0.01) phis[np++] = phi_x;
-    if (slb_solver_frame_values(s, phis, np, vals) != 0) return -1;
-    for (int p = 0; p < np; p++)
-      for (int m = 1; m < host_M + 2; m++)
-        fprintf(f, "%0.5f %0.5f %0.20f\n", phis[p], PhiYmin + host_dPhi * (m - 1),
-                vals[(size_t)p * ncols + (m - 1)]);
-  }
-  free(phis); free(vals);
+  if (for_each_frame_row(s, f, 0, line_frame, NULL) != 0) return -1;
   fprintf(f, "# norm=%0.20f\n", norm);
   printf("# norm=%0.20f\n", norm);
   return 0;
 }
 
+/* display=9 strobe file: this period's frame added to the running image
+ * (reference: src/boltzmann_solver.c:459-484) */
+static int write_strobe(FILE *f, slb_solver *s, float *strobe, const float *a0row, float t)
+{
+  float norm = 0;
+  float dphi_over_2 = host_dPhi / 2.0;
+  for (int m = 1; m < host_M + 1; m++) norm += (a0row[m] + a0row[m]) * dphi_over_2;
+  norm *= 2 * SLB_PI * sqrt(host_alpha);
+  if (for_each_frame_row(s, f, 0, line_strobe, strobe) != 0) return -1;
+  fprintf(f, "# norm=%0.20f\n", norm);
+  fprintf(f, "# t=%0.20f\n", t);
+  printf("# norm=%0.20f\n", norm);
+  return 0;
+}
+
+/* is there display work (averaging, a record, a frame) right after the step taken at
+ * loop time t with this frame_time?  Steps without any may be taken two at a time. */
+static int step_has_work(float t, float frame_time)
+{
+  if (display == 77) return host_E_omega > 0 && frame_time >= 0.01;
+  if (display == 7)  return frame_time >= 0.01 && t > frame_start;
+  if (display == 8)  return 0;
+  if (display == 9 && t >= t_start) return 1;
+  return host_E_omega > 0 && t >= t_start;             /* av() */
+}
+
 int slb_main(int argc, char **argv)
 {
   parse_cmd(argc, argv);
-  if (display == 3 || display == 7 || display == 9) {
-    fprintf(stderr, "ERROR: display=%d is not available in this build; use display=4, 8 or 77.\n", display);
-    return EXIT_FAILURE;
-  }
   HIP_OK(hipSetDevice(device));
 
   float T = host_omega > 0 ? (2 * SLB_PI / host_omega) : 0;   /* period of the a/c field */
-  t_max = t_start + T;
+  float *strobe = NULL;
+  if (display == 9) {                                          /* 101 periods, one strobe image each */
+    t_max = t_start + 101 * T;
+    size_t size = 0;
+    for (float phi_x = -SLB_PI; phi_x < SLB_PI; phi_x += 0.01) size += (size_t)host_M + 1;
+    strobe = (float *)calloc(size, sizeof(float));
+    if (!strobe) { fprintf(stderr, "ERROR: out of host memory for the strobe image\n"); return EXIT_FAILURE; }
+  } else {
+    t_max = t_start + T;
+  }
   if (quiet == 0) printf("# t_max = %0.20f\n", t_max);
 
   slb_derive_and_load();
@@ -149,8 +219,9 @@ int slb_main(int argc, char **argv)
   slb_set_av_mode(avm != NULL && strcmp(avm, "tree") == 0 ? SLB_AV_TREE :
                   avm != NULL && strcmp(avm, "chain") == 0 ? SLB_AV_CHAIN : SLB_AV_EXACT);
 
-  int   progress = 0;
-  float frame_time = 0;
+  int   progress = 0, frame_number = 1;
+  float frame_time = 0, last_tT_reminder = 0;
+  char  file_name[64];
   float t0 = 0, t = 0;
 
   for (;;) {
@@ -160,16 +231,12 @@ int slb_main(int argc, char **argv)
        * the lattices in between are just never stored. */
       if (!two_launches && !one_launch) {
         const float t2 = t + host_dt, ft2 = frame_time + host_dt;
-        const int work1 = host_E_omega > 0 && ((display == 77 && frame_time >= 0.01) ||
-                                               (display != 77 && display != 8 && t >= t_start));
-        const int work2 = host_E_omega > 0 && ((display == 77 && ft2 >= 0.01) ||
-                                               (display != 77 && display != 8 && t2 >= t_start));
-        if (!work1 && !work2 && t2 < t_max) {
+        if (!step_has_work(t, frame_time) && !step_has_work(t2, ft2) && t2 < t_max) {
           s->t = t;                      /* the engine forms both iterations' cosines from its own clock */
           slb_solver_double_step(s);
           t = t2;
           frame_time = ft2 + host_dt;
-          if (out != stdout && quiet == 0 && (progress += 2) >= 300) {
+          if (out != stdout && display != 7 && quiet == 0 && (progress += 2) >= 300) {
             printf("\rt=%0.9f %0.2f%%", t, t / t_max * 100);
             fflush(stdout);
             progress = 0;
@@ -203,7 +270,36 @@ int slb_main(int argc, char **argv)
 
       slb_solver_swap(s);
 
-      if (out != stdout && quiet == 0) {
+      if (display == 9 && t >= t_start) {
+        /* a strobe image whenever t/T wraps (reference: src/boltzmann_solver.c:260-275) */
+        float tT = t / T;
+        float tT_reminder = tT - ((int)tT);
+        if (tT_reminder < last_tT_reminder) {
+          slb_solver_get_rows(s, 1 + s->current, 0, 1, a_rows);
+          sprintf(file_name, "strobe%08d.data", frame_number++);
+          FILE *f = fopen(file_name, "w");
+          if (!f) { perror("ERROR"); return EXIT_FAILURE; }
+          printf("\nWriting strobe %s\n", file_name);
+          const int rc = write_strobe(f, s, strobe, a_rows, t);
+          fclose(f);
+          if (rc != 0) return EXIT_FAILURE;
+          frame_time = 0;
+        }
+        last_tT_reminder = tT_reminder;
+      }
+      if (display == 7 && frame_time >= 0.01 && t > frame_start) {      /* a movie frame */
+        slb_solver_get_rows(s, 1 + s->current, 0, 2, a_rows);
+        sprintf(file_name, "frame%08d.data", frame_number++);
+        FILE *f = fopen(file_name, "w");
+        if (!f) { perror("ERROR"); return EXIT_FAILURE; }
+        printf("\nWriting frame %s\n", file_name);
+        const int rc = write_frame8(f, s, a_rows, pitch, t);
+        fclose(f);
+        if (rc != 0) return EXIT_FAILURE;
+        frame_time = 0;
+      }
+
+      if (out != stdout && display != 7 && quiet == 0) {
         if (++progress >= 300) {
           printf("\rt=%0.9f %0.2f%%", t, t / t_max * 100);
           fflush(stdout);
@@ -218,6 +314,14 @@ int slb_main(int argc, char **argv)
     HIP_OK(hipMemcpy(av6, s->av_data, sizeof(av6), hipMemcpyDeviceToHost));
     const float norm = slb_host_norm(a_rows, host_M, host_dPhi, host_alpha);
 
+    if (display == 3) {
+      /* the final distribution next to the equilibrium one
+       * (reference: src/boltzmann_c_solver.c:219-234) */
+      if (for_each_frame_row(s, out, 1, line_display3, NULL) != 0) return EXIT_FAILURE;
+      fprintf(out, "# norm=%0.20f\n", norm);
+      printf("# norm=%0.20f\n", norm);
+      break;
+    }
     if (display == 8) {
       FILE *f = fopen("frame.data", "w");
       if (!f) { perror("ERROR"); return EXIT_FAILURE; }

@@ -502,12 +502,13 @@ int slb_solver_av_partial(slb_solver *s, double *sums)
   return slb_av_partial(&s->av_slab, s->a[s->current], s->b[s->current], sums);
 }
 
-/* display=8 frame values of this slab's main-lattice columns (main_slab.j_first..j_last;
- * 1..M+1 for a single slab) for nphi values of phi_x: out (host) receives
- * nphi x ncols floats, row p = phi_x[p].  The cos/sin factors come from the host's
+/* Frame values (display=3/7/8/9) of this slab's main-lattice columns (main_slab.j_first..
+ * j_last; 1..M+1 for a single slab) for nphi values of phi_x: out (host) receives
+ * nphi x ncols floats, row p = phi_x[p].  source 0: the current lattice a, b;
+ * source 1: the equilibrium coefficients a0, cosine terms only.  The cos/sin factors come from the host's
  * libm with the argument n*phi_x formed in float, as in the reference
  * (src/boltzmann_solver.c:495-504); the sums run on the device. */
-int slb_solver_frame_values(slb_solver *s, const float *phi_x, int nphi, float *out)
+int slb_solver_frame_values(slb_solver *s, int source, const float *phi_x, int nphi, float *out)
 {
   const int nrows = s->N + 1;
   const int col_first = s->main_slab.j_first;
@@ -528,8 +529,9 @@ int slb_solver_frame_values(slb_solver *s, const float *phi_x, int nphi, float *
   HIP_OK(hipMalloc((void **)&d_out, out_bytes));
   HIP_OK(hipMemcpy(d_tab, tab, tab_bytes, hipMemcpyHostToDevice));
   free(tab);
-  const int rc = slb_frame_values(s->a[s->current], s->b[s->current], s->pitch, nrows, col_first, ncols,
-                                  d_tab, nphi, d_out);
+  const int rc = source == 1
+      ? slb_frame_values(s->a0, NULL, s->pitch, nrows, col_first, ncols, d_tab, nphi, d_out)
+      : slb_frame_values(s->a[s->current], s->b[s->current], s->pitch, nrows, col_first, ncols, d_tab, nphi, d_out);
   if (rc == 0) {
     HIP_OK(hipStreamSynchronize((hipStream_t)slb_get_stream()));
     HIP_OK(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));

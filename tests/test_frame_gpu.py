@@ -44,6 +44,21 @@ def test_frame_values_bit_exact(slb, oracle, N, M, B, omega, steps, nphi):
         orc.close()
 
 
+def test_equilibrium_frame_values_bit_exact(slb, oracle):
+    """source=1: the cosine-only sum over a0 that display=3 prints beside the distribution.
+    The oracle's frame loop with b = 0 adds exact zeros to every term, i.e. the same values."""
+    p, orc, sol = _setup(slb, oracle, 16, 300, 0.4, 10.0, 2)
+    try:
+        phi = oracle.frame_phi_x()[::25]
+        a0 = orc.array("a0")
+        exp = oracle.frame_values(p, a0, np.zeros_like(a0), phi)
+        got = sol.frame_values(phi, source=1)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    finally:
+        sol.close()
+        orc.close()
+
+
 def test_frame_values_entry_point_checks_its_arguments(slb):
     L = slb.lib()
     ok = 0x10000

@@ -86,6 +86,40 @@ def test_program_display8_identical(solver_bin, oracle, tmp_path):
     assert got == exp
 
 
+def test_program_display7_movie_frames_identical(solver_bin, oracle, tmp_path):
+    """display=7: a frame file every 0.01 of time once t > frame-start, same names and text."""
+    args = ["display=7", "omega=100", "B=0.5", "n-harmonics=6", "g-grid=37", "t-max=0.02", "frame-start=0.03"] + COMMON
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
+    names = sorted(f.name for f in odir.glob("frame*.data"))
+    assert names == sorted(f.name for f in gdir.glob("frame*.data")) and len(names) >= 4
+    for n in names:
+        assert (gdir / n).read_text() == (odir / n).read_text(), n
+    assert [l for l in g.stdout.splitlines() if l.startswith("Writing")] == \
+           [l for l in o.stdout.splitlines() if l.startswith("Writing")]
+
+
+def test_program_display9_strobe_identical(solver_bin, oracle, tmp_path):
+    """display=9: 101 periods, one accumulated strobe image per period; the last file
+    carries the sum of all of them."""
+    args = ["display=9", "omega=100", "B=0.5", "n-harmonics=4", "g-grid=13", "t-max=0.02"] + COMMON
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
+    names = sorted(f.name for f in odir.glob("strobe*.data"))
+    assert names == sorted(f.name for f in gdir.glob("strobe*.data")) and len(names) == 101
+    for n in (names[0], names[1], names[50], names[-1]):
+        assert (gdir / n).read_text() == (odir / n).read_text(), n
+    # display=9 keeps averaging as display=4 does, but prints no record
+    assert (gdir / "out.txt").read_text() == (odir / "out.txt").read_text() == ""
+
+
+def test_program_display3_dump_identical(solver_bin, oracle, tmp_path):
+    """display=3: the final distribution and the equilibrium one, columns 1..M-1."""
+    args = ["display=3", "omega=100", "B=0.5", "n-harmonics=8", "g-grid=61", "t-max=0.01"] + COMMON
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
+    got, exp = (gdir / "out.txt").read_text(), (odir / "out.txt").read_text()
+    assert len(exp.splitlines()) == 629 * 60 + 1
+    assert got == exp
+
+
 @pytest.mark.parametrize("N,M,B,omega,steps,n_chunk", [
     (1, 5, 0.5, 3.0, 3, 0), (2, 61, 0.05, 100.0, 6, 0), (7, 300, 0.4, 10.0, 5, 3),
     (32, 4096, 1.0, 1.0, 20, 0), (33, 1000, 0.5, 30.0, 7, 5), (64, 20001, 0.2, 10.0, 6, 16),
