@@ -6,6 +6,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 import scipy.special
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -119,3 +120,18 @@ def test_frame_values_are_what_the_frame_file_holds(oracle, tmp_path):
         assert all(l.split()[2] == "%0.20f" % v for l, v in zip(lines, vals.ravel()))
     finally:
         orc.close()
+
+
+@pytest.mark.parametrize("E_dc", [0.5, 1.0, 2.0])
+def test_esaki_tsu_limit_without_magnetic_field(oracle, tmp_path, E_dc):
+    """A pin that does not come from the reference's output: with B = 0 and no a/c field the
+    model is the one-dimensional superlattice, whose stationary drift velocity is the
+    Esaki-Tsu characteristic v_dr/v_p = 2 E/(1 + E^2) whatever mu is, with norm 1 and no
+    transverse velocity.  The oracle relaxes to it within the discretisation error."""
+    args = ["display=4", f"E_dc={E_dc}", "E_omega=0", "omega=0", "mu=5", "alpha=1", "B=0",
+            "PhiYmin=-4", "PhiYmax=4", "n-harmonics=24", "g-grid=256", "dt=0.001", "t-max=12", "o=out.txt"]
+    oracle.run_cli(args, cwd=tmp_path, threads=4)
+    cols = (tmp_path / "out.txt").read_text().splitlines()[-1].split()
+    v_dr, norm, v_y = float(cols[4]), float(cols[6]), float(cols[7])
+    assert abs(v_dr - 2 * E_dc / (1 + E_dc ** 2)) < 2e-4
+    assert abs(norm - 1) < 1e-4 and abs(v_y) < 1e-6
