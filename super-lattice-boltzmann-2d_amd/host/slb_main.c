@@ -167,6 +167,56 @@ static int write_strobe(FILE *f, slb_solver *s, float *strobe, const float *a0ro
   return 0;
 }
 
+/* av() beside the time loop.  The sums read the main lattice a step has just written;
+ * the following step only reads that lattice too, and the one after it is the first to
+ * write those arrays again.  So av() goes to a stream of its own, ordered after its step
+ * by an event, and runs while the next step is computed; a step waits for the av() issued
+ * two steps before it.  (The exact-order sums keep three compute units busy for about as
+ * long as a step keeps all of them busy; sharing the machine with a step slows them, so
+ * at g-grid 2^20 a step with av() takes about 1.6 ms instead of 2.0, not yet 1.0.) */
+static hipStream_t av_stream = NULL;
+static hipEvent_t  ev_step, ev_av[2];
+static int         av_issued[2] = {0, 0};
+static long        av_index = 0;
+
+static void av_overlap_init(void)
+{
+  /* highest priority: three workgroups that should not queue behind a step's thousands */
+  int prio_low = 0, prio_high = 0;
+  HIP_OK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+  HIP_OK(hipStreamCreateWithPriority(&av_stream, hipStreamNonBlocking, prio_high));
+  HIP_OK(hipEventCreateWithFlags(&ev_step, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&ev_av[0], hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&ev_av[1], hipEventDisableTiming));
+}
+
+/* before a step is launched: the av() that read the arrays this step overwrites */
+static void av_overlap_before_step(int all)
+{
+  const int slot = (int)(av_index & 1);
+  if (av_issued[slot]) HIP_OK(hipStreamWaitEvent(NULL, ev_av[slot], 0));
+  if (all && av_issued[slot ^ 1]) HIP_OK(hipStreamWaitEvent(NULL, ev_av[slot ^ 1], 0));
+}
+
+static void av_overlap_issue(slb_solver *s, float t)
+{
+  const int slot = (int)(av_index & 1);
+  HIP_OK(hipEventRecord(ev_step, NULL));
+  HIP_OK(hipStreamWaitEvent(av_stream, ev_step, 0));
+  slb_set_stream(av_stream);
+  av(0, s->a[s->next], s->b[s->next], s->av_data, t);
+  slb_set_stream(NULL);
+  HIP_OK(hipEventRecord(ev_av[slot], av_stream));
+  av_issued[slot] = 1;
+  av_index++;
+}
+
+static void av_overlap_drain(void)
+{
+  HIP_OK(hipStreamSynchronize(av_stream));
+  av_issued[0] = av_issued[1] = 0;
+}
+
 /* is there display work (averaging, a record, a frame) right after the step taken at
  * loop time t with this frame_time?  Steps without any may be taken two at a time. */
 static int step_has_work(float t, float frame_time)
@@ -200,6 +250,7 @@ int slb_main(int argc, char **argv)
   slb_solver *s = slb_solver_create(0, 1);
   if (!s) return EXIT_FAILURE;
   slb_solver_tiptoe(s);
+  av_overlap_init();
 
   const int pitch = s->pitch;
   float *a_rows = (float *)malloc(sizeof(float) * 3 * (size_t)pitch);
@@ -233,6 +284,7 @@ int slb_main(int argc, char **argv)
         const float t2 = t + host_dt, ft2 = frame_time + host_dt;
         if (!step_has_work(t, frame_time) && !step_has_work(t2, ft2) && t2 < t_max) {
           s->t = t;                      /* the engine forms both iterations' cosines from its own clock */
+          av_overlap_before_step(1);
           slb_solver_double_step(s);
           t = t2;
           frame_time = ft2 + host_dt;
@@ -246,6 +298,7 @@ int slb_main(int argc, char **argv)
       }
       float c[4];
       slb_step_cosines(t, c);
+      av_overlap_before_step(0);
       if (two_launches) {
         slb_solver_sweep_main(s, c[0], c[1]);
         slb_solver_sweep_half(s, c[2], c[3]);
@@ -255,6 +308,7 @@ int slb_main(int argc, char **argv)
       }
 
       if (host_E_omega > 0 && display == 77 && frame_time >= 0.01) {
+        av_overlap_drain();
         av(0, s->a[s->next], s->b[s->next], s->av_data, t);
         slb_solver_get_rows(s, 1 + s->current, 0, 3, a_rows);
         slb_solver_get_rows(s, 5 + s->current, 1, 2, b_rows);
@@ -266,7 +320,7 @@ int slb_main(int argc, char **argv)
         frame_time = 0;
       }
       if (host_E_omega > 0 && display != 7 && display != 77 && display != 8 && t >= t_start)
-        av(0, s->a[s->next], s->b[s->next], s->av_data, t);
+        av_overlap_issue(s, t);
 
       slb_solver_swap(s);
 
@@ -309,6 +363,7 @@ int slb_main(int argc, char **argv)
       frame_time += host_dt;
     }
 
+    av_overlap_drain();
     slb_solver_get_rows(s, 1 + s->current, 0, 2, a_rows);
     slb_solver_get_rows(s, 5 + s->current, 1, 1, b_rows);
     HIP_OK(hipMemcpy(av6, s->av_data, sizeof(av6), hipMemcpyDeviceToHost));
