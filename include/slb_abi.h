@@ -150,6 +150,22 @@ int slb_step_fused2(const slb_step2_geom *geom, const float *a0,
                     float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
                     const float cosines[8]);
 
+/* slb_step_fused2 that also hands out what av() needs of BOTH new main lattices:
+ * rows_first and rows_second (device, [3][pitch] floats each, both or neither)
+ * receive rows 0 and 1 of a and row 1 of b -- as buffer rows 0, 1, 2 -- of the
+ * main lattice after the first and after the second of the two steps, at the
+ * columns those sweeps produce.  The lattice after the first step is stored
+ * nowhere else.  slb_av_sums_exact(slab, rows, rows + pitch, tot) then forms
+ * that step's sums from such a buffer (it looks for b's row 1 at b + pitch,
+ * which is buffer row 2). */
+int slb_step_fused2_rows(const slb_step2_geom *geom, const float *a0,
+                         const float *a_current, const float *b_current,
+                         const float *a_current_hs, const float *b_current_hs,
+                         const float *a_next, const float *b_next,
+                         const float *a_next_hs, const float *b_next_hs,
+                         float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
+                         const float cosines[8], float *rows_first, float *rows_second);
+
 /* Geometry of S = `steps` loop iterations in one launch (1 <= S <= 4): the
  * columns each of the 2S sweeps produces, in execution order (main sweep at t,
  * half-step sweep at t, main sweep at t+dt, ...). */
@@ -199,6 +215,16 @@ int slb_av_partial(const slb_slab *slab, const float *a, const float *b, double 
 /* Second stage of av(): narrow sums[0..2] to float and apply the reference's
  * update of av_data[0..5] at loop time t. */
 int slb_av_update(const double *sums, float *av_data, float t);
+
+/* av() in two calls, for hosts that overlap the sums with later steps: the three
+ * exact-order sums of columns slab->j_first..j_last into tot3[0..2] (device
+ * floats; nothing shared between calls, so several may run on different streams
+ * at once), and the update of av_data[0..5] at loop time t from such sums. */
+int slb_av_sums_exact(const slb_slab *slab, const float *a, const float *b, float *tot3);
+/* the same for n <= 4 lattices in one launch (a[k], b[k] -> tot3[k]) */
+int slb_av_sums_exact_n(const slb_slab *slab, int n, const float *const a[], const float *const b[],
+                        float *const tot3[]);
+int slb_av_update_exact(const float *tot3, float *av_data, float t);
 
 /* How av() forms its three sums:
  *   SLB_AV_EXACT (default) -- the terms are added in float in the reference's

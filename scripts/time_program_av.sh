@@ -8,7 +8,7 @@ ARGS="display=4 E_dc=1 E_omega=0.1 mu=5 alpha=1 PhiYmin=-4 PhiYmax=4 dt=0.001 n-
 for mode in exact chain tree; do
   for omega in 100 10; do
     s=$(date +%s%N)
-    SLB_AV=$mode timeout -k 10 300 bin/boltzmann_solver $ARGS omega=$omega > /dev/null
+    SLB_TIMING=1 SLB_AV=$mode timeout -k 10 300 bin/boltzmann_solver $ARGS omega=$omega > /dev/null
     e=$(date +%s%N)
     echo "SLB_AV=$mode omega=$omega: $(( (e - s) / 1000000 )) ms   $(tail -1 /tmp/slb_time.txt | cut -d' ' -f5,6,10)"
   done

@@ -613,13 +613,17 @@ struct Fused2Args {
   const float *a0, *a_c, *b_c, *a_h, *b_h;   // a0; main lattice (t); half-step lattice (t+dt/2)
   const float *p1a, *p1b, *p2a, *p2b;        // never-written cells of the in-between lattices
   float *a_o, *b_o, *a_ho, *b_ho;            // main lattice (t+2dt); half-step lattice (t+5dt/2)
+  float *rows1, *rows2;                      // ROWS: [3][pitch] each: a rows 0, 1 and b row 1 of stage A's / C's output
   float E_dc, E_omega, B, dt, dPhi, PhiYmin, nu, nu2, nu_tilde, bdt;
   float c[8];                                // cosines: stage A 0,1  B 2,3  C 4,5  D 6,7
   int N, pitch, m_offset, n_chunk, jj0;
   int jf[4], jl[4];                          // columns stage A, B, C, D produce
 };
 
-template <bool PF, int MINW, bool DIAG = false>
+// ROWS: the three rows av() reads (a rows 0 and 1, b row 1) of BOTH new main lattices are
+// also written to small side buffers, so the harmonic sums of the in-between time step can
+// be formed although that lattice itself is never stored.
+template <bool PF, int MINW, bool DIAG = false, bool ROWS = false>
 __global__ void __launch_bounds__(256, MINW)
 fused2_step_kernel(const Fused2Args p)
 {
@@ -740,6 +744,17 @@ fused2_step_kernel(const Fused2Args p)
       widen(cur.hA, ea); widen(cur.hB, eb);
       diffs(hA_p, dla);  diffs(hB_p, dlb);
       stage(r, s[0], s[1], cur.a0, cur.ac, cur.bc, ea, eb, dla, dlb, o1A, o1B);
+      if constexpr (ROWS) {
+        if (r <= 1 && n0 == 0 && interior) {
+#pragma unroll
+          for (int k = 0; k < V; k++) {
+            if (flags & (1u << k)) {
+              p.rows1[(size_t)r * P + j + k] = o1A[k];
+              if (r == 1) p.rows1[2 * P + j + k] = o1B[k];
+            }
+          }
+        }
+      }
       if (need1) keep_old(p.p1a, p.p1b, (size_t)r * P, flags, o1A, o1B);
     } else if (r == p.N) {
       load4(p.p1a, (size_t)r * P, o1A); load4(p.p1b, (size_t)r * P, o1B);
@@ -777,6 +792,17 @@ fused2_step_kernel(const Fused2Args p)
             if (flags & (1u << (12 + k))) {
               p.a_o[row + j + k] = o3A[k];
               if (rc > 0) p.b_o[row + j + k] = o3B[k];
+            }
+          }
+        }
+        if constexpr (ROWS) {
+          if (rc <= 1) {
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+              if (flags & (1u << (12 + k))) {
+                p.rows2[row + j + k] = o3A[k];
+                if (rc == 1) p.rows2[2 * P + j + k] = o3B[k];
+              }
             }
           }
         }
@@ -1047,6 +1073,28 @@ __device__ __forceinline__ float av_term(const AvArgs &p, int q, int j)
   return p.a[j] * phi * p.dPhi;
 }
 
+// up to four lattices' sums in one launch: workgroup 3*set + q forms sum q of lattice `set`
+constexpr int kAvMaxSets = 4;
+struct AvSets {
+  AvArgs geom;                       // a, b unused
+  const float *a[kAvMaxSets], *b[kAvMaxSets];
+  float *tot[kAvMaxSets];
+};
+__device__ __forceinline__ AvArgs av_set_args(const AvSets &s, int set)
+{
+  AvArgs p = s.geom;
+#pragma unroll
+  for (int k = 0; k < kAvMaxSets; k++) if (k == set) { p.a = s.a[k]; p.b = s.b[k]; }
+  return p;
+}
+__device__ __forceinline__ float *av_set_tot(const AvSets &s, int set)
+{
+  float *t = s.tot[0];
+#pragma unroll
+  for (int k = 1; k < kAvMaxSets; k++) if (k == set) t = s.tot[k];
+  return t;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -1118,11 +1166,14 @@ __global__ void av_update_kernel(const double *sums, float *av_data, double cos_
 // additions is the cost (about 8 cycles per column on gfx950), which is why the
 // three sums run as three workgroups: waves of one workgroup can end up on the
 // same SIMD and then take turns.  A one-lane kernel applies the update.
-__global__ void __launch_bounds__(64) av_exact_kernel(const AvArgs p, float *tot)
+__global__ void __launch_bounds__(64) av_exact_kernel(const AvSets sets)
 {
   constexpr int T = 16, B = 64 * T;                  // columns per group
   __shared__ __attribute__((aligned(16))) float park[B];
-  const int q    = blockIdx.x;
+  const int set = blockIdx.x / 3;
+  const int q   = blockIdx.x % 3;
+  const AvArgs p = av_set_args(sets, set);
+  float *tot = av_set_tot(sets, set);
   const int lane = threadIdx.x;
   float acc = 0.0f;
   float term[T];
@@ -1354,15 +1405,16 @@ __device__ float seq_sum_block(F term, int n, ScanShared<W, T> &sh, int *stats =
   return acc;
 }
 
-// exact mode, parallel form: workgroup q forms sum q
+// exact mode, parallel form
 constexpr int kAvScanWaves = 8, kAvScanPerLane = 8;     // fastest of the shapes tried at 2^20 columns
-__global__ void __launch_bounds__(64 * kAvScanWaves) av_exact_scan_kernel(const AvArgs p, float *tot)
+__global__ void __launch_bounds__(64 * kAvScanWaves) av_exact_scan_kernel(const AvSets sets)
 {
   __shared__ ScanShared<kAvScanWaves, kAvScanPerLane> sh;
-  const int q = blockIdx.x;
+  const int set = blockIdx.x / 3, q = blockIdx.x % 3;
+  const AvArgs p = av_set_args(sets, set);
   const float acc = seq_sum_block<kAvScanWaves, kAvScanPerLane>(
       [&](int i) { return av_term(p, q, p.j_first + i); }, p.j_last - p.j_first + 1, sh);
-  if (threadIdx.x == 0) tot[q] = acc;
+  if (threadIdx.x == 0) av_set_tot(sets, set)[q] = acc;
 }
 
 template <int W, int T>
@@ -1475,7 +1527,7 @@ int launch_fused(FusedArgs &args, int block)
   return (int)hipGetLastError();
 }
 
-template <bool PF, int MINW, bool DIAG = false>
+template <bool PF, int MINW, bool DIAG = false, bool ROWS = false>
 int launch_fused2(Fused2Args &args, int block)
 {
   int lo = args.jf[0], hi = args.jl[0];
@@ -1485,7 +1537,7 @@ int launch_fused2(Fused2Args &args, int block)
   const int waves = (hi + 1 - args.jj0 + per_wave - 1) / per_wave;
   const int wpb = block / 64;
   dim3 grid((waves + wpb - 1) / wpb, (args.N + args.n_chunk - 1) / args.n_chunk);
-  hipLaunchKernelGGL((fused2_step_kernel<PF, MINW, DIAG>), grid, dim3(block), 0, g_stream, args);
+  hipLaunchKernelGGL((fused2_step_kernel<PF, MINW, DIAG, ROWS>), grid, dim3(block), 0, g_stream, args);
   return (int)hipGetLastError();
 }
 
@@ -1673,6 +1725,22 @@ int slb_step_fused2(const slb_step2_geom *g, const float *a0,
                     float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
                     const float cosines[8])
 {
+  return slb_step_fused2_rows(g, a0, a_current, b_current, a_current_hs, b_current_hs, a_next, b_next,
+                              a_next_hs, b_next_hs, a_out, b_out, a_out_hs, b_out_hs, cosines, nullptr, nullptr);
+}
+
+int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
+                         const float *a_current, const float *b_current,
+                         const float *a_current_hs, const float *b_current_hs,
+                         const float *a_next, const float *b_next,
+                         const float *a_next_hs, const float *b_next_hs,
+                         float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
+                         const float cosines[8], float *rows_first, float *rows_second)
+{
+  if ((rows_first == nullptr) != (rows_second == nullptr)) {
+    fprintf(stderr, "slb_step_fused2_rows: both row buffers or neither\n");
+    return -1;
+  }
   if (!g_phys.loaded) { fprintf(stderr, "slb_step_fused2: load_data() has not been called\n"); return -1; }
   if (!g || g->pitch < 4 || g->pitch % 4 != 0 || g_phys.N < 1) { fprintf(stderr, "slb_step_fused2: bad geometry\n"); return -1; }
   for (int q = 0; q < 4; q++) {
@@ -1694,6 +1762,7 @@ int slb_step_fused2(const slb_step2_geom *g, const float *a0,
   s.a0 = a0; s.a_c = a_current; s.b_c = b_current; s.a_h = a_current_hs; s.b_h = b_current_hs;
   s.p1a = a_next; s.p1b = b_next; s.p2a = a_next_hs; s.p2b = b_next_hs;
   s.a_o = a_out; s.b_o = b_out; s.a_ho = a_out_hs; s.b_ho = b_out_hs;
+  s.rows1 = rows_first; s.rows2 = rows_second;
   s.E_dc = g_phys.E_dc; s.E_omega = g_phys.E_omega; s.B = g_phys.B; s.dt = g_phys.dt;
   s.dPhi = g_phys.dPhi; s.PhiYmin = g_phys.PhiYmin; s.nu = g_phys.nu; s.nu2 = g_phys.nu2;
   s.nu_tilde = g_phys.nu_tilde; s.bdt = g_phys.bdt;
@@ -1715,6 +1784,7 @@ int slb_step_fused2(const slb_step2_geom *g, const float *a0,
   }
   if (n_chunk > s.N) n_chunk = s.N;
   s.n_chunk = n_chunk;
+  if (rows_first) return launch_fused2<false, 3, false, true>(s, block);
   switch (g_variant) {
     case 21: return launch_fused2<false, 2>(s, block);
     case 22: return launch_fused2<true, 2>(s, block);
@@ -1904,6 +1974,41 @@ int slb_av_update(const double *sums, float *av_data, float t)
   return (int)hipGetLastError();
 }
 
+int slb_av_sums_exact_n(const slb_slab *slab, int n, const float *const a[], const float *const b[],
+                        float *const tot3[])
+{
+  if (!g_phys.loaded || !slab || slab->j_first < 0 || slab->j_last >= slab->pitch ||
+      n < 1 || n > kAvMaxSets || !a || !b || !tot3) return -1;
+  AvSets sets;
+  sets.geom = make_av_args(slab, nullptr, nullptr);
+  for (int k = 0; k < kAvMaxSets; k++) {
+    const int src = k < n ? k : 0;
+    if (!a[src] || !b[src] || !tot3[src]) return -1;
+    sets.a[k] = a[src]; sets.b[k] = b[src]; sets.tot[k] = tot3[src];
+  }
+  // both kernels give the CPU's bits; below a few ten thousand columns the one-lane chain is
+  // done before the parallel form has paid for its passes
+  if (g_av_mode == SLB_AV_CHAIN || slab->j_last - slab->j_first < 32768)
+    hipLaunchKernelGGL(av_exact_kernel, dim3(3 * n), dim3(64), 0, g_stream, sets);
+  else
+    hipLaunchKernelGGL(av_exact_scan_kernel, dim3(3 * n), dim3(64 * kAvScanWaves), 0, g_stream, sets);
+  return (int)hipGetLastError();
+}
+
+int slb_av_sums_exact(const slb_slab *slab, const float *a, const float *b, float *tot3)
+{
+  return slb_av_sums_exact_n(slab, 1, &a, &b, &tot3);
+}
+
+int slb_av_update_exact(const float *tot3, float *av_data, float t)
+{
+  if (!g_phys.loaded || !tot3 || !av_data) return -1;
+  const float wt = g_phys.omega * t;            // float product, as the reference forms it
+  hipLaunchKernelGGL(av_update_exact_kernel, dim3(1), dim3(64), 0, g_stream, tot3, av_data,
+                     cos((double)wt), sin((double)wt), g_phys.dt);
+  return (int)hipGetLastError();
+}
+
 void av(int blocks, float *a, float *b, float *av_data, float t)
 {
   (void)blocks;
@@ -1915,18 +2020,11 @@ void av(int blocks, float *a, float *b, float *av_data, float t)
     if (rc == 0) rc = slb_av_partial(&slab, a, b, g_ws + kMaxAvBlocks * 3);
     if (rc == 0) rc = slb_av_update(g_ws + kMaxAvBlocks * 3, av_data, t);
   } else {
-    const AvArgs p = make_av_args(&slab, a, b);
-    const float wt = g_phys.omega * t;
     rc = ensure_workspace();
     if (rc == 0) {
       float *tot = reinterpret_cast<float *>(g_ws + kMaxAvBlocks * 3);   // 4 doubles kept for totals
-      // both give the CPU's bits; below a few ten thousand columns the one-lane chain is
-      // done before the parallel form has paid for its passes
-      if (g_av_mode == SLB_AV_CHAIN || p.j_last - p.j_first < 32768) hipLaunchKernelGGL(av_exact_kernel, dim3(3), dim3(64), 0, g_stream, p, tot);
-      else hipLaunchKernelGGL(av_exact_scan_kernel, dim3(3), dim3(64 * kAvScanWaves), 0, g_stream, p, tot);
-      hipLaunchKernelGGL(av_update_exact_kernel, dim3(1), dim3(64), 0, g_stream, (const float *)tot, av_data,
-                         cos((double)wt), sin((double)wt), g_phys.dt);
-      rc = (int)hipGetLastError();
+      rc = slb_av_sums_exact(&slab, a, b, tot);
+      if (rc == 0) rc = slb_av_update_exact(tot, av_data, t);
     }
   }
   if (rc > 0) HandleError(rc, __FILE__, __LINE__);

@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "slb_host.h"
 
@@ -167,70 +168,117 @@ static int write_strobe(FILE *f, slb_solver *s, float *strobe, const float *a0ro
   return 0;
 }
 
-/* av() beside the time loop.  The sums read the main lattice a step has just written;
- * the following step only reads that lattice too, and the one after it is the first to
- * write those arrays again.  So av() goes to a stream of its own, ordered after its step
- * by an event, and runs while the next step is computed; a step waits for the av() issued
- * two steps before it.  (The exact-order sums keep three compute units busy for about as
- * long as a step keeps all of them busy; sharing the machine with a step slows them, so
- * at g-grid 2^20 a step with av() takes about 1.6 ms instead of 2.0, not yet 1.0.) */
-static hipStream_t av_stream = NULL;
-static hipEvent_t  ev_step, ev_av[2];
-static int         av_issued[2] = {0, 0};
+/* av() beside the time loop.  The sums need three rows of the main lattice a step has
+ * written (a rows 0 and 1, b row 1).  Those rows go into a slot of a small ring -- written
+ * by the double-step kernel itself for both of its iterations, or copied after a single
+ * step -- so that the time loop never has to wait for the sums: each step's sums run on one
+ * of a few streams of their own (the exact-order sums keep three compute units busy for
+ * about as long as a step keeps all of them busy, and the sums of different steps do not
+ * depend on each other), and one more stream applies the running-average updates in step
+ * order.  A slot is reused only after its update is done. */
+#define AV_SLOTS       32
+#define AV_SUM_STREAMS 16
+static struct { float *rows, *tot; double *sums; hipEvent_t ev_sums, ev_upd; int used; } av_slot[AV_SLOTS];
+static hipStream_t av_sum_stream[AV_SUM_STREAMS], av_upd_stream;
+static int         av_streams = 3;            /* sum streams in use (SLB_AV_STREAMS=1..16) */
+static hipEvent_t  ev_rows;
 static long        av_index = 0;
+static int         av_tree = 0;
+static slb_slab    av_cols;
 
-static void av_overlap_init(void)
+static void av_ring_init(const slb_solver *s)
 {
-  /* highest priority: three workgroups that should not queue behind a step's thousands */
-  int prio_low = 0, prio_high = 0;
-  HIP_OK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-  HIP_OK(hipStreamCreateWithPriority(&av_stream, hipStreamNonBlocking, prio_high));
-  HIP_OK(hipEventCreateWithFlags(&ev_step, hipEventDisableTiming));
-  HIP_OK(hipEventCreateWithFlags(&ev_av[0], hipEventDisableTiming));
-  HIP_OK(hipEventCreateWithFlags(&ev_av[1], hipEventDisableTiming));
+  const size_t row_bytes = sizeof(float) * (size_t)s->pitch;
+  for (int k = 0; k < AV_SLOTS; k++) {
+    HIP_OK(hipMalloc((void **)&av_slot[k].rows, 3 * row_bytes));
+    HIP_OK(hipMemset(av_slot[k].rows, 0, 3 * row_bytes));
+    HIP_OK(hipMalloc((void **)&av_slot[k].tot, 4 * sizeof(float)));
+    HIP_OK(hipMalloc((void **)&av_slot[k].sums, 4 * sizeof(double)));
+    HIP_OK(hipEventCreateWithFlags(&av_slot[k].ev_sums, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&av_slot[k].ev_upd, hipEventDisableTiming));
+    av_slot[k].used = 0;
+  }
+  for (int k = 0; k < AV_SUM_STREAMS; k++)
+    HIP_OK(hipStreamCreateWithFlags(&av_sum_stream[k], hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&av_upd_stream, hipStreamNonBlocking));
+  HIP_OK(hipEventCreateWithFlags(&ev_rows, hipEventDisableTiming));
+  /* columns 1..M, i.e. m < TMSIZE (reference: src/boltzmann_c_solver.c:417) */
+  av_cols.pitch = s->pitch; av_cols.m_offset = 0; av_cols.j_first = 1; av_cols.j_last = host_TMSIZE - 1;
 }
 
-/* before a step is launched: the av() that read the arrays this step overwrites */
-static void av_overlap_before_step(int all)
+/* the slot the av() number av_index + ahead will use; the time loop's stream waits until
+ * the slot's previous occupant has been summed and applied */
+static float *av_ring_acquire(int ahead)
 {
-  const int slot = (int)(av_index & 1);
-  if (av_issued[slot]) HIP_OK(hipStreamWaitEvent(NULL, ev_av[slot], 0));
-  if (all && av_issued[slot ^ 1]) HIP_OK(hipStreamWaitEvent(NULL, ev_av[slot ^ 1], 0));
+  const int k = (int)((av_index + ahead) % AV_SLOTS);
+  if (av_slot[k].used) HIP_OK(hipStreamWaitEvent(NULL, av_slot[k].ev_upd, 0));
+  return av_slot[k].rows;
 }
 
-static void av_overlap_issue(slb_solver *s, float t)
+/* the next n (1 or 2) slots' rows have been queued on the time loop's stream: queue their
+ * sums (one launch) and their updates of av_data for the loop times t[0..n-1] */
+static void av_ring_submit(slb_solver *s, int n, const float *t)
 {
-  const int slot = (int)(av_index & 1);
-  HIP_OK(hipEventRecord(ev_step, NULL));
-  HIP_OK(hipStreamWaitEvent(av_stream, ev_step, 0));
-  slb_set_stream(av_stream);
-  av(0, s->a[s->next], s->b[s->next], s->av_data, t);
+  hipStream_t st = av_sum_stream[av_tree ? 0 : (av_index / 2) % av_streams];   /* the tree sums share a workspace */
+  const float *a[2], *b[2];
+  float *tot[2];
+  int slot[2], rc = 0;
+  for (int i = 0; i < n; i++) {
+    slot[i] = (int)((av_index + i) % AV_SLOTS);
+    a[i] = av_slot[slot[i]].rows; b[i] = a[i] + s->pitch; tot[i] = av_slot[slot[i]].tot;
+  }
+  HIP_OK(hipEventRecord(ev_rows, NULL));
+  HIP_OK(hipStreamWaitEvent(st, ev_rows, 0));
+  slb_set_stream(st);
+  if (av_tree) for (int i = 0; i < n && rc == 0; i++) rc = slb_av_partial(&av_cols, a[i], b[i], av_slot[slot[i]].sums);
+  else         rc = slb_av_sums_exact_n(&av_cols, n, a, b, tot);
+  if (rc != 0) { fprintf(stderr, "ERROR: av sums failed (%d)\n", rc); exit(EXIT_FAILURE); }
+  HIP_OK(hipEventRecord(av_slot[slot[0]].ev_sums, st));
+  HIP_OK(hipStreamWaitEvent(av_upd_stream, av_slot[slot[0]].ev_sums, 0));
+  slb_set_stream(av_upd_stream);
+  for (int i = 0; i < n && rc == 0; i++) {
+    rc = av_tree ? slb_av_update(av_slot[slot[i]].sums, s->av_data, t[i])
+                 : slb_av_update_exact(av_slot[slot[i]].tot, s->av_data, t[i]);
+    HIP_OK(hipEventRecord(av_slot[slot[i]].ev_upd, av_upd_stream));
+    av_slot[slot[i]].used = 1;
+  }
+  if (rc != 0) { fprintf(stderr, "ERROR: av update failed (%d)\n", rc); exit(EXIT_FAILURE); }
   slb_set_stream(NULL);
-  HIP_OK(hipEventRecord(ev_av[slot], av_stream));
-  av_issued[slot] = 1;
-  av_index++;
+  av_index += n;
 }
 
-static void av_overlap_drain(void)
+/* after a single step: copy the three rows of the lattice it wrote, then as above */
+static void av_ring_copy_and_submit(slb_solver *s, float t)
 {
-  HIP_OK(hipStreamSynchronize(av_stream));
-  av_issued[0] = av_issued[1] = 0;
+  const size_t row_bytes = sizeof(float) * (size_t)s->pitch;
+  float *rows = av_ring_acquire(0);
+  HIP_OK(hipMemcpyAsync(rows, s->a[s->next], 2 * row_bytes, hipMemcpyDeviceToDevice, NULL));
+  HIP_OK(hipMemcpyAsync(rows + 2 * (size_t)s->pitch, s->b[s->next] + s->pitch, row_bytes,
+                        hipMemcpyDeviceToDevice, NULL));
+  av_ring_submit(s, 1, &t);
 }
 
-/* is there display work (averaging, a record, a frame) right after the step taken at
- * loop time t with this frame_time?  Steps without any may be taken two at a time. */
-static int step_has_work(float t, float frame_time)
+static void av_ring_drain(void)
 {
-  if (display == 77) return host_E_omega > 0 && frame_time >= 0.01;
-  if (display == 7)  return frame_time >= 0.01 && t > frame_start;
+  HIP_OK(hipStreamSynchronize(av_upd_stream));      /* updates are in step order: the last one ends it all */
+  for (int k = 0; k < AV_SLOTS; k++) av_slot[k].used = 0;
+}
+
+/* What follows the step taken at loop time t with this frame_time: 0 nothing, 1 only
+ * av(), 2 a record, a frame or a strobe test.  Two steps of kind 0 or 1 may share a launch. */
+static int step_kind(float t, float frame_time)
+{
+  if (display == 77) return host_E_omega > 0 && frame_time >= 0.01 ? 2 : 0;
+  if (display == 7)  return frame_time >= 0.01 && t > frame_start ? 2 : 0;
   if (display == 8)  return 0;
-  if (display == 9 && t >= t_start) return 1;
-  return host_E_omega > 0 && t >= t_start;             /* av() */
+  if (display == 9 && t >= t_start) return 2;
+  return host_E_omega > 0 && t >= t_start ? 1 : 0;     /* av() */
 }
 
 int slb_main(int argc, char **argv)
 {
   parse_cmd(argc, argv);
+  av_streams = 3;
   HIP_OK(hipSetDevice(device));
 
   float T = host_omega > 0 ? (2 * SLB_PI / host_omega) : 0;   /* period of the a/c field */
@@ -250,7 +298,7 @@ int slb_main(int argc, char **argv)
   slb_solver *s = slb_solver_create(0, 1);
   if (!s) return EXIT_FAILURE;
   slb_solver_tiptoe(s);
-  av_overlap_init();
+  av_ring_init(s);
 
   const int pitch = s->pitch;
   float *a_rows = (float *)malloc(sizeof(float) * 3 * (size_t)pitch);
@@ -267,7 +315,12 @@ int slb_main(int argc, char **argv)
    * exact-order sums (bit-identical to the CPU solver; about 1 ms at g-grid 2^20);
    * SLB_AV=chain: the exact sums by one lane adding term after term (cross-check) */
   const char *avm = getenv("SLB_AV");
-  slb_set_av_mode(avm != NULL && strcmp(avm, "tree") == 0 ? SLB_AV_TREE :
+  av_tree = avm != NULL && strcmp(avm, "tree") == 0;
+  if (getenv("SLB_AV_STREAMS") != NULL) {
+    av_streams = atoi(getenv("SLB_AV_STREAMS"));
+    av_streams = av_streams < 1 ? 1 : (av_streams > AV_SUM_STREAMS ? AV_SUM_STREAMS : av_streams);
+  }
+  slb_set_av_mode(av_tree ? SLB_AV_TREE :
                   avm != NULL && strcmp(avm, "chain") == 0 ? SLB_AV_CHAIN : SLB_AV_EXACT);
 
   int   progress = 0, frame_number = 1;
@@ -275,18 +328,34 @@ int slb_main(int argc, char **argv)
   char  file_name[64];
   float t0 = 0, t = 0;
 
+  /* SLB_TIMING=1: wall time of every pass of the time loop, on stderr */
+  const int timing = getenv("SLB_TIMING") != NULL;
+
   for (;;) {
-    for (t = t0; t < t_max; t += host_dt) {
-      /* Two iterations in one launch whenever neither of them has display work
-       * (averaging or a display=77 record) and both lie before t_max: same bits,
-       * the lattices in between are just never stored. */
+    struct timespec w0, w1;
+    long loop_steps = 0;
+    if (timing) { HIP_OK(hipDeviceSynchronize()); clock_gettime(CLOCK_MONOTONIC, &w0); }
+    for (t = t0; t < t_max; t += host_dt, loop_steps++) {
+      /* Two iterations in one launch whenever neither of them has display work beyond
+       * av() and both lie before t_max: same bits, the lattices in between are just never
+       * stored (the rows av() reads of them are). */
       if (!two_launches && !one_launch) {
         const float t2 = t + host_dt, ft2 = frame_time + host_dt;
-        if (!step_has_work(t, frame_time) && !step_has_work(t2, ft2) && t2 < t_max) {
+        const int k1 = step_kind(t, frame_time), k2 = step_kind(t2, ft2);
+        if (k1 < 2 && k2 < 2 && t2 < t_max) {
           s->t = t;                      /* the engine forms both iterations' cosines from its own clock */
-          av_overlap_before_step(1);
-          slb_solver_double_step(s);
+          if (k1 == 0 && k2 == 0) {
+            slb_solver_double_step(s);
+          } else {
+            /* av() after both iterations, or only after the second when t_start falls
+             * between them (the first iteration's rows then land in a slot nobody reads) */
+            float *ra = av_ring_acquire(0), *rb = av_ring_acquire(1);
+            slb_solver_double_step_rows(s, k1 ? ra : rb, k1 ? rb : ra);
+            const float tt[2] = {k1 ? t : t2, t2};
+            av_ring_submit(s, k1 + k2, tt);
+          }
           t = t2;
+          loop_steps++;
           frame_time = ft2 + host_dt;
           if (out != stdout && display != 7 && quiet == 0 && (progress += 2) >= 300) {
             printf("\rt=%0.9f %0.2f%%", t, t / t_max * 100);
@@ -298,7 +367,6 @@ int slb_main(int argc, char **argv)
       }
       float c[4];
       slb_step_cosines(t, c);
-      av_overlap_before_step(0);
       if (two_launches) {
         slb_solver_sweep_main(s, c[0], c[1]);
         slb_solver_sweep_half(s, c[2], c[3]);
@@ -308,7 +376,7 @@ int slb_main(int argc, char **argv)
       }
 
       if (host_E_omega > 0 && display == 77 && frame_time >= 0.01) {
-        av_overlap_drain();
+        av_ring_drain();
         av(0, s->a[s->next], s->b[s->next], s->av_data, t);
         slb_solver_get_rows(s, 1 + s->current, 0, 3, a_rows);
         slb_solver_get_rows(s, 5 + s->current, 1, 2, b_rows);
@@ -320,7 +388,7 @@ int slb_main(int argc, char **argv)
         frame_time = 0;
       }
       if (host_E_omega > 0 && display != 7 && display != 77 && display != 8 && t >= t_start)
-        av_overlap_issue(s, t);
+        av_ring_copy_and_submit(s, t);
 
       slb_solver_swap(s);
 
@@ -363,7 +431,14 @@ int slb_main(int argc, char **argv)
       frame_time += host_dt;
     }
 
-    av_overlap_drain();
+    av_ring_drain();
+    if (timing) {
+      HIP_OK(hipDeviceSynchronize());
+      clock_gettime(CLOCK_MONOTONIC, &w1);
+      const double sec = (double)(w1.tv_sec - w0.tv_sec) + 1e-9 * (double)(w1.tv_nsec - w0.tv_nsec);
+      fprintf(stderr, "# time loop: %ld iterations in %.4f s (%.4f ms each)\n", loop_steps, sec,
+              loop_steps ? 1e3 * sec / loop_steps : 0.0);
+    }
     slb_solver_get_rows(s, 1 + s->current, 0, 2, a_rows);
     slb_solver_get_rows(s, 5 + s->current, 1, 1, b_rows);
     HIP_OK(hipMemcpy(av6, s->av_data, sizeof(av6), hipMemcpyDeviceToHost));

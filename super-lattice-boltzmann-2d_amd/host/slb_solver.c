@@ -273,7 +273,16 @@ static void sync_spares(slb_solver *s)
  * zone next to a neighbour, not into a global boundary column.  Results go to
  * the spare arrays; slb_solver_double_step_finish() makes them current.
  * c[0..3] = cosines of the first iteration, c[4..7] of the second. */
+static void double_step_range_rows(slb_solver *s, int j_first, int j_last, const float c[8],
+                                   float *rows_first, float *rows_second);
+
 void slb_solver_double_step_range(slb_solver *s, int j_first, int j_last, const float c[8])
+{
+  double_step_range_rows(s, j_first, j_last, c, NULL, NULL);
+}
+
+static void double_step_range_rows(slb_solver *s, int j_first, int j_last, const float c[8],
+                                   float *rows_first, float *rows_second)
 {
   if (!s->spare_a || s->spare_of != s->current || s->spare_of_hs != s->current_hs) sync_spares(s);
   const int G = s->G, first = s->rank == 0, last = s->rank == s->nranks - 1;
@@ -293,10 +302,11 @@ void slb_solver_double_step_range(slb_solver *s, int j_first, int j_last, const 
     g.j_first[q] = g.j_first[q + 1] - 1 > lo[q] ? g.j_first[q + 1] - 1 : lo[q];
     g.j_last[q]  = g.j_last[q + 1] + 1 < hi[q] ? g.j_last[q + 1] + 1 : hi[q];
   }
-  check_sweep(slb_step_fused2(&g, s->a0, s->a[s->current], s->b[s->current],
-                              s->a[s->current_hs], s->b[s->current_hs],
-                              s->a[s->next], s->b[s->next], s->a[s->next_hs], s->b[s->next_hs],
-                              s->spare_a, s->spare_b, s->spare_ah, s->spare_bh, c), __LINE__);
+  check_sweep(slb_step_fused2_rows(&g, s->a0, s->a[s->current], s->b[s->current],
+                                   s->a[s->current_hs], s->b[s->current_hs],
+                                   s->a[s->next], s->b[s->next], s->a[s->next_hs], s->b[s->next_hs],
+                                   s->spare_a, s->spare_b, s->spare_ah, s->spare_bh, c,
+                                   rows_first, rows_second), __LINE__);
 }
 
 /* after two iterations the ping-pong indices are back where they were; the
@@ -324,6 +334,17 @@ void slb_solver_double_step(slb_solver *s)
   float c[8];
   slb_step2_cosines(s->t, c);
   slb_solver_double_step_range(s, s->half_slab.j_first, s->half_slab.j_last, c);
+  slb_solver_double_step_finish(s);
+}
+
+/* A double step that also leaves, in two [3][pitch] device buffers, the rows av() reads
+ * (a rows 0 and 1, b row 1) of the main lattice after the first and after the second
+ * iteration: averaging can then go on while two iterations share a launch. */
+void slb_solver_double_step_rows(slb_solver *s, float *rows_first, float *rows_second)
+{
+  float c[8];
+  slb_step2_cosines(s->t, c);
+  double_step_range_rows(s, s->half_slab.j_first, s->half_slab.j_last, c, rows_first, rows_second);
   slb_solver_double_step_finish(s);
 }
 
