@@ -758,6 +758,15 @@ fused2_step_kernel(const Fused2Args p)
       if (need1) keep_old(p.p1a, p.p1b, (size_t)r * P, flags, o1A, o1B);
     } else if (r == p.N) {
       load4(p.p1a, (size_t)r * P, o1A); load4(p.p1b, (size_t)r * P, o1B);
+      if constexpr (ROWS) {
+        // a single harmonic: row 1 is the row no sweep writes, and av() reads it all the same
+        if (r == 1 && n0 == 0 && interior) {
+#pragma unroll
+          for (int k = 0; k < V; k++) {
+            if (flags & (1u << k)) { p.rows1[P + j + k] = o1A[k]; p.rows1[2 * P + j + k] = o1B[k]; }
+          }
+        }
+      }
     }
 
     // ---- stage B: half-step sweep at t, row r-1 ----
@@ -810,6 +819,14 @@ fused2_step_kernel(const Fused2Args p)
       if (need3) keep_old(p.a_o, p.b_o, row, flags >> 8, o3A, o3B);
     } else if (rc == p.N) {
       load4(p.a_o, (size_t)rc * P, o3A); load4(p.b_o, (size_t)rc * P, o3B);
+      if constexpr (ROWS) {
+        if (rc == 1 && n0 == 0) {
+#pragma unroll
+          for (int k = 0; k < V; k++) {
+            if (flags & (1u << (12 + k))) { p.rows2[P + j + k] = o3A[k]; p.rows2[2 * P + j + k] = o3B[k]; }
+          }
+        }
+      }
     }
 
     // ---- stage D: half-step sweep at t+dt, row r-3 (stored) ----

@@ -262,3 +262,52 @@ def test_multi_step_bit_exact(slb, oracle, S, N, M, B, omega, n_chunk):
         L.slb_set_tuning(0, 0, 0)
         sol.close()
         orc.close()
+
+
+@pytest.mark.parametrize("N,M,B,omega", [(1, 5, 0.5, 3.0), (8, 61, 0.05, 100.0), (32, 4096, 1.0, 1.0),
+                                         (64, 40001, 0.1, 10.0)])
+def test_double_step_hands_out_the_rows_av_reads(slb, oracle, N, M, B, omega):
+    """slb_step_fused2_rows: the side buffers hold a rows 0, 1 and b row 1 of the main lattice
+    after the first iteration (stored nowhere else) and after the second, bit for bit; the
+    exact sums formed from them are the oracle's av() for those two lattices."""
+    import ctypes as C
+    import torch
+    p = oracle.make_params(N=N, M=M, B=B, omega=omega)
+    slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    orc = oracle.OracleState(p)
+    sol = slb.Solver()
+    L = slb.lib()
+    try:
+        sol.tiptoe()
+        for _ in range(2):
+            sol.double_step()
+        orc.step(4)
+        pitch = sol.s.pitch
+        rows = [torch.zeros((3, pitch), dtype=torch.float32, device="cuda") for _ in range(2)]
+        av_dev = torch.zeros(6, dtype=torch.float32, device="cuda")
+        tot = [torch.zeros(4, dtype=torch.float32, device="cuda") for _ in range(2)]
+        av_cpu = np.zeros(6, np.float32)
+        sol.double_step_rows(rows[0].data_ptr(), rows[1].data_ptr())
+        slab = slb.Slab(pitch, 0, 1, M)
+        a_ptrs = (C.c_void_p * 2)(rows[0].data_ptr(), rows[1].data_ptr())
+        b_ptrs = (C.c_void_p * 2)(rows[0].data_ptr() + 4 * pitch, rows[1].data_ptr() + 4 * pitch)
+        t_ptrs = (C.c_void_p * 2)(tot[0].data_ptr(), tot[1].data_ptr())
+        L.slb_av_sums_exact_n.argtypes = [C.POINTER(slb.Slab), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        assert L.slb_av_sums_exact_n(C.byref(slab), 2, a_ptrs, b_ptrs, t_ptrs) == 0
+        for k in range(2):
+            t_k = np.float32(orc.st.t)
+            orc.step(1)
+            cur = orc.st.current
+            a, b = orc.array("a", cur), orc.array("b", cur)
+            got = rows[k].cpu().numpy()
+            for r, exp in ((0, a[0]), (1, a[1]), (2, b[1])):
+                assert np.array_equal(got[r, 1:M + 2].view(np.uint32), exp[1:M + 2].view(np.uint32)), (k, r)
+            oracle.lib().orc_av(C.byref(p), a, b, av_cpu, t_k)
+            assert L.slb_av_update_exact(tot[k].data_ptr(), av_dev.data_ptr(), t_k) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(av_dev.cpu().numpy().view(np.uint32), av_cpu.view(np.uint32))
+        _compare_live_state(sol, orc, M)
+    finally:
+        sol.close()
+        orc.close()
