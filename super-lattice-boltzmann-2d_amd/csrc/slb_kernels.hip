@@ -1508,6 +1508,23 @@ int ensure_workspace()
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Rows per workgroup when the caller leaves it to the library.  A wave walks its rows one
+// after the other, so a launch lasts at least as long as one chunk's row loop: wide
+// lattices (a thousand workgroups across already) take the chunk length measured fastest
+// at full size, narrower ones are cut into shorter chunks -- down to 4 rows -- until about
+// a thousand workgroups exist, because there the row loop is all the launch costs.
+int auto_chunk(int N, int cols, int cols_per_wave, int block, int full_size_chunk)
+{
+  const int waves = (cols + cols_per_wave - 1) / cols_per_wave;
+  const int wgs_x = (waves + block / 64 - 1) / (block / 64);
+  int chunks = (1024 + wgs_x - 1) / wgs_x;
+  const int most = N / 4 > 0 ? N / 4 : 1;
+  if (chunks > most) chunks = most;
+  int nc = (N + chunks - 1) / chunks;
+  if (nc > full_size_chunk) nc = full_size_chunk;
+  return nc < 1 ? 1 : nc;
+}
+
 template <int V, int XCH>
 int launch_sweep(SweepArgs &args, int block)
 {
@@ -1660,7 +1677,7 @@ int slb_sweep(const slb_slab *slab,
   // fastest on MI355X at every large shape tried (waves of different chunks run out of phase),
   // and narrow lattices need the extra workgroups to fill 256 CUs
   int n_chunk = g_n_chunk;
-  if (n_chunk <= 0) n_chunk = 16;
+  if (n_chunk <= 0) n_chunk = auto_chunk(s.N, s.j_last - s.j_first + 1, variant == 1 ? 64 : 256, block, 16);
   if (n_chunk > s.N) n_chunk = s.N;
   s.n_chunk = n_chunk;
 
@@ -1713,11 +1730,9 @@ int slb_step_fused(const slb_step_geom *g,
   // narrow lattices need the extra workgroups anyway.
   int n_chunk = g_n_chunk;
   if (n_chunk <= 0) {
-    // a launch only a few columns wide (a slab's edge range) is a handful of waves whose
-    // run time is the length of their row loop: short chunks finish it sooner
     const int lo = s.j1_first < s.j2_first ? s.j1_first : s.j2_first;
     const int hi = s.j1_last > s.j2_last ? s.j1_last : s.j2_last;
-    n_chunk = hi - lo < 4 * 248 ? 4 : 16;
+    n_chunk = auto_chunk(s.N, hi - lo + 1, 248, block, 16);
   }
   if (n_chunk > s.N) n_chunk = s.N;
   s.n_chunk = n_chunk;
@@ -1793,11 +1808,9 @@ int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
   // 32-row chunks measured fastest at n-harmonics 128, g-grid 2^20
   int n_chunk = g_n_chunk;
   if (n_chunk <= 0) {
-    // a launch only a few columns wide (a slab's edge range) is a handful of waves whose
-    // run time is the length of their row loop: short chunks finish it sooner
     int lo = s.jf[0], hi = s.jl[0];
     for (int q = 1; q < 4; q++) { lo = s.jf[q] < lo ? s.jf[q] : lo; hi = s.jl[q] > hi ? s.jl[q] : hi; }
-    n_chunk = hi - lo < 4 * 248 ? 4 : 32;
+    n_chunk = auto_chunk(s.N, hi - lo + 1, 248, block, 32);
   }
   if (n_chunk > s.N) n_chunk = s.N;
   s.n_chunk = n_chunk;
