@@ -49,6 +49,36 @@ def cpu_baseline(n_harm, g_grid, phys, steps):
                       f"(OpenMP over phi_y, {threads} threads), after 1 untimed step"}
 
 
+def config1_case(slb, torch):
+    """The reference's own CPU-runnable case (n-harmonics=32, g-grid=4096, B=1, omega=1): the
+    GPU time loop (two steps per launch) next to the serial CPU oracle, for orientation."""
+    import oracle_binding as ob
+    n_harm, g_grid, steps = 32, 4096, 2000
+    phys = dict(E_dc=1.0, E_omega=0.1, omega=1.0, mu=5.0, alpha=1.0, B=1.0, PhiYmin=-4.0, PhiYmax=4.0, dt=0.001)
+    slb.configure(N=n_harm, M=g_grid, t_start=10.0, **phys)
+    sol = slb.Solver(0, 1)
+    sol.tiptoe()
+    sol.set_fused(2)
+    sol.double_step()
+    sol.run_timed(100)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sol.run_timed(steps)
+    torch.cuda.synchronize()
+    gpu = n_harm * g_grid * steps / (time.perf_counter() - t0)
+    sol.close()
+    st = ob.OracleState(ob.make_params(N=n_harm, M=g_grid, **phys), threads=1)
+    st.step(10)
+    cpu_steps = 300
+    t0 = time.perf_counter()
+    st.step(cpu_steps)
+    cpu = n_harm * g_grid * cpu_steps / (time.perf_counter() - t0)
+    st.close()
+    return {"workload": f"n-harmonics={n_harm} g-grid={g_grid} B=1 omega=1 dt=0.001",
+            "gpu_value": gpu, "cpu_serial_value": cpu, "unit": "lattice-point-updates/s",
+            "gpu_steps": steps, "cpu_steps": cpu_steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +215,7 @@ def main():
                                "algorithmic_bytes_per_launch": alg_bytes}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(n_harm, g_grid, phys, args.cpu_steps)
+            out["config1"] = config1_case(slb, torch)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
