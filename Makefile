@@ -1,6 +1,8 @@
 # Build of the MI355X (gfx950) solver.
 #   make            -> super-lattice-boltzmann-2d_amd/libslb2d.so, bin/boltzmann_solver, oracle
 #   make lib        -> the library only
+#   make EXTRA=-DSLB_TIMING_VARIANTS  -> also the kernel variants with the arithmetic removed
+#                      (tuning variants 97-99: memory floors for scripts/tune.py, wrong results)
 # The kernels need separately rounded mul/add in the reference's order:
 # -ffp-contract=off, no fast-math.  Host C is built like the reference's host
 # (gnu99, -O3, no -march: reference GNUmakefile:36).
@@ -10,7 +12,8 @@ CC      ?= gcc
 PKG     := super-lattice-boltzmann-2d_amd
 LIB     := $(PKG)/libslb2d.so
 
-HIPFLAGS := --offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 -Wall
+EXTRA   ?=
+HIPFLAGS := --offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 -Wall $(EXTRA)
 CFLAGS   := -std=gnu99 -O3 -fPIC -ffp-contract=off -Wall -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include
 
 HOST_SRC := $(PKG)/host/slb_globals.c $(PKG)/host/slb_bessel.c $(PKG)/host/slb_cli.c \

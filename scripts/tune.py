@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Sweep-kernel tuning grid on one GPU: variant x n_chunk x block at a given shape.
-Prints ms per sweep launch and the algorithmic GB/s (28 B per point-sweep)."""
+Prints ms per sweep launch and the algorithmic GB/s (28 B per point-sweep).
+Variants 97, 98, 99 (the same kernels with the arithmetic removed: their memory floors)
+exist only in a library built with `make EXTRA=-DSLB_TIMING_VARIANTS`; elsewhere those
+numbers select the default kernel."""
 import argparse
 import importlib
 import os

@@ -1744,7 +1744,9 @@ int slb_step_fused(const slb_step_geom *g,
     case 10: return launch_fused<false, false, 5>(s, block);
     case 11: return launch_fused<true, false, 5>(s, block);
     case 12: return launch_fused<false, false, 6>(s, block);
-    case 99: return launch_fused<false, false, 4, true>(s, block);   // timing only, wrong results
+#ifdef SLB_TIMING_VARIANTS
+    case 99: return launch_fused<false, false, 4, true>(s, block);   // arithmetic removed: memory floor, wrong results
+#endif
     default: return launch_fused<false, false, 4>(s, block);
   }
 }
@@ -1821,7 +1823,9 @@ int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
     case 23: return launch_fused2<false, 3>(s, block);
     case 24: return launch_fused2<true, 3>(s, block);
     case 25: return launch_fused2<false, 4>(s, block);
-    case 98: return launch_fused2<false, 3, true>(s, block);   // timing only, wrong results
+#ifdef SLB_TIMING_VARIANTS
+    case 98: return launch_fused2<false, 3, true>(s, block);   // arithmetic removed: memory floor, wrong results
+#endif
     default: return launch_fused2<false, 3>(s, block);
   }
 }
@@ -1850,14 +1854,20 @@ int slb_step_multi(const slb_multi_geom *g, const float *a0, const float *const 
   const int block = g_block > 0 ? g_block : 256;
   if (block % 64 != 0 || block > 256) { fprintf(stderr, "slb_step_multi: block must be 64, 128, 192 or 256\n"); return -1; }
   const int n_chunk = g_n_chunk > 0 ? g_n_chunk : 64;
-  const int v = g_variant;
   // waves per SIMD the register allocator is held to: measured best per S on MI355X
   switch (g->steps) {
     case 1: return launch_multi<1, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+#ifdef SLB_TIMING_VARIANTS
+#define v g_variant
     case 2: return v == 97 ? launch_multi<2, 3, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
                            : launch_multi<2, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
     case 3: return v == 97 ? launch_multi<3, 2, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
                            : launch_multi<3, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+#undef v
+#else
+    case 2: return launch_multi<2, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+    case 3: return launch_multi<3, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+#endif
     default: return launch_multi<4, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
   }
 }
