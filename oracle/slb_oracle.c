@@ -457,6 +457,31 @@ int orc_solver_run(orc_state *s, int display, FILE *out, FILE *log, long max_ste
   return 0;
 }
 
+/* read-from=stdin: one of E_dc, E_omega, omega, mu, alpha, B is replaced and the run goes
+ * on from the present state for `timeout` more time units plus one period
+ * (reference: src/boltzmann_solver.c:384-393, the host in which the new value reaches the
+ * sweeps; the derived constants are refreshed as well, so a new B really is the new B).
+ * t_max is formed with the OLD period, as there.  Returns 0, or -1 for an unknown name. */
+int orc_solver_continue(orc_state *s, const char *name, float value, float timeout)
+{
+  orc_params *p = &s->p;
+  int known = 1;
+  if      (!strcmp(name, "E_dc"))    p->E_dc = value;
+  else if (!strcmp(name, "E_omega")) p->E_omega = value;
+  else if (!strcmp(name, "omega"))   p->omega = value;
+  else if (!strcmp(name, "mu"))      p->mu = value;
+  else if (!strcmp(name, "alpha"))   p->alpha = value;
+  else if (!strcmp(name, "B"))       p->B = value;
+  else known = 0;
+  p->t_start = s->t + timeout;
+  s->t_max = p->t_start + s->T;
+  s->t0 = s->t + p->dt;
+  s->T = p->omega > 0 ? (2 * ORC_PI / p->omega) : 0;
+  orc_derive(p);
+  memset(s->av_data, 0, sizeof(s->av_data));
+  return known ? 0 : -1;
+}
+
 /* A float running sum in index order: the shape of every sum in av() and in the
  * display reductions (reference: src/boltzmann_c_solver.c:417-423). */
 float orc_seq_sum(const float *x, long n)

@@ -105,6 +105,11 @@ void orc_state_step(orc_state *s);
  * (reference: src/boltzmann_solver.c:255-287).  max_steps<0 means "run to t_max". */
 int orc_solver_run(orc_state *s, int display, FILE *out, FILE *log, long max_steps);
 
+/* read-from=stdin record "name value timeout": replace one of E_dc, E_omega, omega, mu,
+ * alpha, B, and arrange for orc_solver_run() to go on from the present state
+ * (reference: src/boltzmann_solver.c:384-393). */
+int orc_solver_continue(orc_state *s, const char *name, float value, float timeout);
+
 /* frame-start= for display=7 (frames are written only for t > frame_start) */
 void orc_set_frame_start(float t);
 

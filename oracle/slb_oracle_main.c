@@ -15,7 +15,7 @@ int main(int argc, char **argv)
 {
   orc_params p;
   memset(&p, 0, sizeof(p));
-  int display = -999, threads = 1;
+  int display = -999, threads = 1, from_stdin = 0;
   long max_steps = -1;
   const char *o = "-";
   p.N = -999; p.M = 3069; p.dt = 0.001;
@@ -43,6 +43,7 @@ int main(int argc, char **argv)
     else if (!strcmp(k, "threads"))     threads   = atoi(v);
     else if (!strcmp(k, "max-steps"))   max_steps = atol(v);
     else if (!strcmp(k, "frame-start")) orc_set_frame_start(strtod(v, NULL));
+    else if (!strcmp(k, "read-from"))   from_stdin = !strcmp(v, "stdin");
   }
   if (display < -900 || p.N < -900 || p.E_dc < -900 || p.E_omega < -900 || p.omega < -900 ||
       p.mu < -900 || p.alpha < -900 || p.PhiYmin < -900 || p.PhiYmax < -900 || p.B < -900 ||
@@ -61,6 +62,16 @@ int main(int argc, char **argv)
   orc_state s;
   if (orc_state_init(&s, &p) != 0) { fprintf(stderr, "ERROR: out of memory\n"); return EXIT_FAILURE; }
   int rc = orc_solver_run(&s, display, out, stdout, max_steps);
+  while (rc == 0 && from_stdin && display != 3 && display != 8) {
+    /* "name value timeout" records; "exit" or end of input ends the run */
+    char name[80];
+    float value, timeout;
+    const int got = fscanf(stdin, "%79s %f %f", name, &value, &timeout);
+    if (got == EOF || (got == 1 && !strcmp(name, "exit"))) break;
+    if (got != 3) continue;
+    orc_solver_continue(&s, name, value, timeout);
+    rc = orc_solver_run(&s, display, out, stdout, max_steps);
+  }
   if (out != stdout && out != stderr) fclose(out);
   orc_state_free(&s);
   return rc == 0 ? EXIT_SUCCESS : EXIT_FAILURE;

@@ -120,7 +120,7 @@ def frame_values(p, a, b, phi_x):
     return out
 
 
-def run_cli(args, threads=8, timeout=600, cwd=None):
+def run_cli(args, threads=8, timeout=600, cwd=None, stdin_text=None):
     lib()
     return subprocess.run([CLI] + list(args) + [f"threads={threads}"], check=True, timeout=timeout,
-                          capture_output=True, text=True, cwd=cwd)
+                          capture_output=True, text=True, cwd=cwd, input=stdin_text)

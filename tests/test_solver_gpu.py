@@ -46,12 +46,13 @@ def test_engine_fields_bit_exact(slb, oracle, N, M, B, omega, steps):
         orc.close()
 
 
-def _run_both(solver_bin, oracle, tmp_path, args, extra_files=()):
+def _run_both(solver_bin, oracle, tmp_path, args, extra_files=(), stdin_text=None, env=None):
     gdir, odir = tmp_path / "gpu", tmp_path / "orc"
     gdir.mkdir(), odir.mkdir()
-    g = subprocess.run([solver_bin] + args + ["o=out.txt"], cwd=gdir, capture_output=True, text=True, timeout=600)
+    g = subprocess.run([solver_bin] + args + ["o=out.txt"], cwd=gdir, capture_output=True, text=True, timeout=600,
+                       input=stdin_text, env=None if env is None else {**os.environ, **env})
     assert g.returncode == 0, g.stdout + g.stderr
-    o = oracle.run_cli(args + ["o=out.txt"], cwd=odir)
+    o = oracle.run_cli(args + ["o=out.txt"], cwd=odir, stdin_text=stdin_text)
     return gdir, odir, g, o
 
 
@@ -84,6 +85,23 @@ def test_program_display8_identical(solver_bin, oracle, tmp_path):
     got, exp = (gdir / "frame.data").read_text(), (odir / "frame.data").read_text()
     assert len(exp.splitlines()) == 629 * 62 + 2
     assert got == exp
+
+
+@pytest.mark.parametrize("form", ["double", "fused", "sweeps"])
+def test_program_read_from_stdin_goes_on_with_new_parameters(solver_bin, oracle, tmp_path, form):
+    """read-from=stdin: after each display=4 record one parameter is replaced and the run
+    continues from the present state (new E_dc, new B with its derived constant, new omega
+    with the old period still in t_max); every record equals the oracle's."""
+    args = ["display=4", "omega=100", "B=0.5", "n-harmonics=8", "g-grid=253", "t-max=0.02",
+            "read-from=stdin"] + COMMON
+    records = "E_dc 1.5 0.02\nB 0.4 0.013\nomega 50 0.01\nbogus 1 0.005\nexit\n"
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args, stdin_text=records,
+                                 env=None if form == "double" else {"SLB_FORM": form})
+    got, exp = (gdir / "out.txt").read_text(), (odir / "out.txt").read_text()
+    assert len(exp.splitlines()) == 15            # five records of three lines
+    assert got == exp
+    pick = lambda s: [l for l in s.splitlines() if l.startswith("# t_max")]
+    assert pick(g.stdout) == pick(o.stdout) and len(pick(o.stdout)) == 5
 
 
 def test_program_display7_movie_frames_identical(solver_bin, oracle, tmp_path):
