@@ -105,11 +105,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     torch.zeros(1, device="cuda")              # make this device current for the C library too
+    # SLB_DIST_BACKEND=gloo: rehearsal of the multi-rank path where RCCL cannot run (several
+    # ranks on one GPU); halo messages are then staged through host memory
+    backend = os.environ.get("SLB_DIST_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     n_harm = args.n_harmonics
     g_grid = args.g_grid_per_gpu * world
@@ -165,7 +171,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
-        w = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        w = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
         run.close()
