@@ -269,13 +269,15 @@ int slb_seq_sum_stats(const float *x, int n, float *out, int *stats);
 void  slb_set_stream(void *hip_stream);
 void *slb_get_stream(void);
 
-/* Sweep kernel selection: variant 0 = auto, 1 = one column per lane,
- * 2 = four columns per lane with neighbour columns re-read through L1,
- * 3 = four columns per lane with neighbour columns taken from the adjacent
- * lanes (cross-lane), 4 = software-pipelined form of 2, 5 = 4 with nontemporal
- * accesses for data touched once.  For slb_step_fused: 6 = plain accesses,
- * anything else = nontemporal.
- * n_chunk = rows per workgroup in n (0 = auto), block = threads (0 = auto). */
+/* Kernel selection and launch shape, for tuning; 0 = let the library choose.
+ * variant, slb_sweep: 1 = one column per lane (any pitch), 2 = four columns per
+ *   lane with neighbour columns re-read through L1, 3 = neighbour columns from
+ *   the adjacent lanes, 4 = software-pipelined form of 2, 5 = 4 with nontemporal
+ *   accesses for data touched once (the default where rows are 16-byte aligned).
+ * variant, slb_step_fused: 6 = plain accesses (default), 7 = nontemporal.
+ * variant, slb_step_fused2: 21 / 23 (default) / 25 = register budget of 2 / 3 / 4
+ *   waves per SIMD.  slb_seq_sum: 41..47 = other workgroup shapes.
+ * n_chunk = rows per workgroup in n (0: by lattice width), block = threads (0: 256). */
 void slb_set_tuning(int variant, int n_chunk, int block);
 
 /* Library / device identification for logs: returns a static string. */

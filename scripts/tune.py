@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--chunks", default="0,8,16,32,64,128")
     ap.add_argument("--blocks", default="256,128,64")
     ap.add_argument("--fused", action="store_true", help="time the one-launch step (variants 6, 7)")
-    ap.add_argument("--double", action="store_true", help="time the double step (variants 21-25)")
+    ap.add_argument("--double", action="store_true", help="time the double step (variants 21, 23, 25)")
     ap.add_argument("--multi", type=int, default=0, help="time the S-steps-per-launch kernel (S = 1..4)")
     args = ap.parse_args()
     import torch

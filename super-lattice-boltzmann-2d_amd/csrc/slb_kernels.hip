@@ -413,7 +413,7 @@ __device__ __forceinline__ void point_update_sel(
   }
 }
 
-template <bool NT, bool PF, int MINW, bool DIAG = false>
+template <bool NT, int MINW, bool DIAG = false>
 __global__ void __launch_bounds__(256, MINW)
 fused_step_kernel(const FusedArgs p)
 {
@@ -490,19 +490,14 @@ fused_step_kernel(const FusedArgs p)
     in.hA[0] = va.x; in.hA[1] = va.y; in.hA[2] = va.z; in.hA[3] = va.w;
     in.hB[0] = vb.x; in.hB[1] = vb.y; in.hB[2] = vb.z; in.hB[3] = vb.w;
   };
-  RowIn cur = {}, nxt = {};
-  if constexpr (PF) { if (r_lo < p.N) load_row(r_lo, cur); }
+  RowIn cur = {};
 
   for (int r = r_lo; r <= r_end; r++) {
     float o1A[V], o1B[V];          // main-sweep output row r, own columns
     const size_t row = (size_t)r * P;
-    if constexpr (PF) {
-      // next row's loads go out before this row is computed
-      if (r + 1 <= r_end && r + 1 < p.N) load_row(r + 1, nxt);
-    }
     if (r < p.N) {
       // ---- main sweep, row r ----
-      if constexpr (!PF) load_row(r, cur);
+      load_row(r, cur);
       float ea[6], eb[6], la[6], lb[6];
       widen(cur.hA, ea); widen(cur.hB, eb);       // row r+1 with its m+-1 neighbours
       widen(hA_p, la);   widen(hB_p, lb);         // row r-1 likewise
@@ -583,7 +578,6 @@ fused_step_kernel(const FusedArgs p)
       hA_c[k] = cur.hA[k]; hB_c[k] = cur.hB[k];
       a0_p[k] = cur.a0[k];
     }
-    if constexpr (PF) cur = nxt;
   }
 }
 
@@ -623,7 +617,7 @@ struct Fused2Args {
 // ROWS: the three rows av() reads (a rows 0 and 1, b row 1) of BOTH new main lattices are
 // also written to small side buffers, so the harmonic sums of the in-between time step can
 // be formed although that lattice itself is never stored.
-template <bool PF, int MINW, bool DIAG = false, bool ROWS = false>
+template <int MINW, bool DIAG = false, bool ROWS = false>
 __global__ void __launch_bounds__(256, MINW)
 fused2_step_kernel(const Fused2Args p)
 {
@@ -730,16 +724,14 @@ fused2_step_kernel(const Fused2Args p)
     load4(p.a0, row, in.a0); load4(p.a_c, row, in.ac); load4(p.b_c, row, in.bc);
     load4(p.a_h, row + P, in.hA); load4(p.b_h, row + P, in.hB);
   };
-  RowIn cur = {}, nxt = {};
-  if constexpr (PF) { if (a_lo < p.N) load_row(a_lo, cur); }
+  RowIn cur = {};
 
   for (int r = a_lo; r <= r_end; r++) {
-    if constexpr (PF) { if (r + 1 <= r_end && r + 1 < p.N) load_row(r + 1, nxt); }
 
     // ---- stage A: main sweep at t, row r ----
     float o1A[V] = {}, o1B[V] = {};
     if (r < p.N) {
-      if constexpr (!PF) load_row(r, cur);
+      load_row(r, cur);
       float ea[6], eb[6], dla[V], dlb[V];
       widen(cur.hA, ea); widen(cur.hB, eb);
       diffs(hA_p, dla);  diffs(hB_p, dlb);
@@ -861,7 +853,6 @@ fused2_step_kernel(const Fused2Args p)
       a0_3[k] = a0_2[k]; a0_2[k] = a0_1[k]; a0_1[k] = cur.a0[k];
       hA_p[k] = hA_c[k]; hB_p[k] = hB_c[k]; hA_c[k] = cur.hA[k]; hB_c[k] = cur.hB[k];
     }
-    if constexpr (PF) cur = nxt;
   }
 }
 
@@ -1547,7 +1538,7 @@ int launch_pipe(SweepArgs &args, int block)
   return (int)hipGetLastError();
 }
 
-template <bool NT, bool PF, int MINW, bool DIAG = false>
+template <bool NT, int MINW, bool DIAG = false>
 int launch_fused(FusedArgs &args, int block)
 {
   const int lo = args.j1_first < args.j2_first ? args.j1_first : args.j2_first;
@@ -1557,11 +1548,11 @@ int launch_fused(FusedArgs &args, int block)
   const int waves = (hi + 1 - args.jj0 + per_wave - 1) / per_wave;
   const int wpb = block / 64;
   dim3 grid((waves + wpb - 1) / wpb, (args.N + args.n_chunk - 1) / args.n_chunk);
-  hipLaunchKernelGGL((fused_step_kernel<NT, PF, MINW, DIAG>), grid, dim3(block), 0, g_stream, args);
+  hipLaunchKernelGGL((fused_step_kernel<NT, MINW, DIAG>), grid, dim3(block), 0, g_stream, args);
   return (int)hipGetLastError();
 }
 
-template <bool PF, int MINW, bool DIAG = false, bool ROWS = false>
+template <int MINW, bool DIAG = false, bool ROWS = false>
 int launch_fused2(Fused2Args &args, int block)
 {
   int lo = args.jf[0], hi = args.jl[0];
@@ -1571,7 +1562,7 @@ int launch_fused2(Fused2Args &args, int block)
   const int waves = (hi + 1 - args.jj0 + per_wave - 1) / per_wave;
   const int wpb = block / 64;
   dim3 grid((waves + wpb - 1) / wpb, (args.N + args.n_chunk - 1) / args.n_chunk);
-  hipLaunchKernelGGL((fused2_step_kernel<PF, MINW, DIAG, ROWS>), grid, dim3(block), 0, g_stream, args);
+  hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS>), grid, dim3(block), 0, g_stream, args);
   return (int)hipGetLastError();
 }
 
@@ -1737,17 +1728,12 @@ int slb_step_fused(const slb_step_geom *g,
   if (n_chunk > s.N) n_chunk = s.N;
   s.n_chunk = n_chunk;
   switch (g_variant) {
-    case 6:  return launch_fused<false, false, 4>(s, block);
-    case 7:  return launch_fused<true, false, 4>(s, block);
-    case 8:  return launch_fused<false, true, 3>(s, block);
-    case 9:  return launch_fused<true, true, 3>(s, block);
-    case 10: return launch_fused<false, false, 5>(s, block);
-    case 11: return launch_fused<true, false, 5>(s, block);
-    case 12: return launch_fused<false, false, 6>(s, block);
+    case 6:  return launch_fused<false, 4>(s, block);
+    case 7:  return launch_fused<true, 4>(s, block);      // nontemporal accesses for data touched once
 #ifdef SLB_TIMING_VARIANTS
-    case 99: return launch_fused<false, false, 4, true>(s, block);   // arithmetic removed: memory floor, wrong results
+    case 99: return launch_fused<false, 4, true>(s, block);   // arithmetic removed: memory floor, wrong results
 #endif
-    default: return launch_fused<false, false, 4>(s, block);
+    default: return launch_fused<false, 4>(s, block);
   }
 }
 
@@ -1816,17 +1802,15 @@ int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
   }
   if (n_chunk > s.N) n_chunk = s.N;
   s.n_chunk = n_chunk;
-  if (rows_first) return launch_fused2<false, 3, false, true>(s, block);
+  if (rows_first) return launch_fused2<3, false, true>(s, block);
   switch (g_variant) {
-    case 21: return launch_fused2<false, 2>(s, block);
-    case 22: return launch_fused2<true, 2>(s, block);
-    case 23: return launch_fused2<false, 3>(s, block);
-    case 24: return launch_fused2<true, 3>(s, block);
-    case 25: return launch_fused2<false, 4>(s, block);
+    case 21: return launch_fused2<2>(s, block);           // register budget of 2, 3 (default), 4 waves per SIMD
+    case 23: return launch_fused2<3>(s, block);
+    case 25: return launch_fused2<4>(s, block);
 #ifdef SLB_TIMING_VARIANTS
-    case 98: return launch_fused2<false, 3, true>(s, block);   // arithmetic removed: memory floor, wrong results
+    case 98: return launch_fused2<3, true>(s, block);   // arithmetic removed: memory floor, wrong results
 #endif
-    default: return launch_fused2<false, 3>(s, block);
+    default: return launch_fused2<3>(s, block);
   }
 }
 
