@@ -85,3 +85,40 @@ def test_av_modes_agree_with_cpu(slb, oracle, M):
             assert np.array_equal(av_dev.cpu().numpy().view(np.uint32), av_cpu.view(np.uint32)), mode
     finally:
         L.slb_set_av_mode(slb.SLB_AV_EXACT)
+
+
+def test_seq_sum_fuzz(slb, oracle):
+    """Many random term streams of assorted shapes: magnitudes spread over a few to sixty
+    binades, runs of equal terms, sign patterns, sparse large terms, cancellation."""
+    import torch
+    rng = np.random.default_rng(77)
+    L = slb.lib()
+    L.slb_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    out = torch.zeros(1, dtype=torch.float32, device="cuda")
+    for case in range(120):
+        n = int(rng.choice([1, 7, 64, 1000, 4095, 4096, 4097, 9000, 33000, 70001]))
+        kind = case % 6
+        if kind == 0:
+            x = rng.standard_normal(n) * 2.0 ** rng.uniform(-20, 20)
+        elif kind == 1:
+            x = rng.standard_normal(n) * 2.0 ** rng.uniform(-60, 0, n)
+        elif kind == 2:                                   # multiples of a power of two: ties everywhere
+            x = rng.integers(-64, 65, n) * 2.0 ** float(rng.integers(-30, 5))
+        elif kind == 3:                                   # smooth bump, like the solver's rows
+            t = np.linspace(-4, 4, n)
+            x = np.exp(-rng.uniform(0.5, 5) * t * t) * rng.choice([1.0, -1.0]) * (8.0 / n)
+            if case % 12 == 3:
+                x = x * t
+        elif kind == 4:                                   # mostly tiny, a few huge
+            x = rng.standard_normal(n) * 1e-6
+            x[rng.integers(0, n, max(1, n // 500))] = rng.standard_normal(max(1, n // 500)) * 1e6
+        else:                                             # pairs that cancel exactly, shuffled a little
+            h = rng.standard_normal((n + 1) // 2)
+            x = np.concatenate([h, -h])[:n]
+            rng.shuffle(x[: n // 3])
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        exp = oracle.seq_sum(x)
+        dev = torch.from_numpy(x).cuda()
+        assert L.slb_seq_sum(dev.data_ptr(), n, out.data_ptr()) == 0
+        got = out.cpu().numpy()
+        assert got.view(np.uint32)[0] == np.array([exp], np.float32).view(np.uint32)[0], (case, kind, n, got[0], exp)
