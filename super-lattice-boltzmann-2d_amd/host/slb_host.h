@@ -168,6 +168,12 @@ void slb_host_display77_sums(const float *a_rows012, const float *b_rows12, int 
                              float out3[3]);
 void slb_host_multipliers(float k3[3]);
 
+/* the display=4 record written to `out` (reference: src/boltzmann_solver.c:348-380):
+ * a01 = rows 0 and 1 of a, b1 = row 1 of b (row pitch `pitch`), av6 = averaging data
+ * (rescaled in place), T = period of the a/c field; and the closing of `out` */
+void slb_write_display4(float norm, const float *a01, const float *b1, int pitch, float *av6, float T);
+void slb_close_output(void);
+
 /* the whole program behind main() */
 int slb_main(int argc, char **argv);
 

@@ -55,9 +55,10 @@ static void write_frame77(float norm, const float *a012, const float *b12, int p
           s3[2], av6[1], av6[2], av6[3], cos(host_omega * t) * s3[0], t, av6[4]);
 }
 
-/* the display=4 record (reference: src/boltzmann_solver.c:348-380) */
-static void write_display4(float norm, const float *a01, const float *b1, int pitch,
-                           float *av6, float T)
+/* the display=4 record (reference: src/boltzmann_solver.c:348-380); a01 = rows 0 and 1 of
+ * a, b1 = row 1 of b, both with row pitch `pitch`; av6 = the averaging data, rescaled in place */
+void slb_write_display4(float norm, const float *a01, const float *b1, int pitch,
+                        float *av6, float T)
 {
   if (quiet == 0) printf("\n# norm=%0.20f\n", norm);
   float s3[3], k3[3];
@@ -222,7 +223,7 @@ static void av_ring_submit(slb_solver *s, int n, const float *t)
   hipStream_t st = av_sum_stream[av_tree ? 0 : (av_index / 2) % av_streams];   /* the tree sums share a workspace */
   const float *a[2], *b[2];
   float *tot[2];
-  int slot[2], rc = 0;
+  int slot[2] = {0, 0}, rc = 0;
   for (int i = 0; i < n; i++) {
     slot[i] = (int)((av_index + i) % AV_SLOTS);
     a[i] = av_slot[slot[i]].rows; b[i] = a[i] + s->pitch; tot[i] = av_slot[slot[i]].tot;
@@ -273,6 +274,12 @@ static int step_kind(float t, float frame_time)
   if (display == 8)  return 0;
   if (display == 9 && t >= t_start) return 2;
   return host_E_omega > 0 && t >= t_start ? 1 : 0;     /* av() */
+}
+
+void slb_close_output(void)
+{
+  if (out != NULL && out != stdout && out != stderr) fclose(out);
+  out = NULL;
 }
 
 int slb_main(int argc, char **argv)
@@ -461,7 +468,7 @@ int slb_main(int argc, char **argv)
       if (rc != 0) return EXIT_FAILURE;
       break;
     }
-    if (display == 4) write_display4(norm, a_rows, b_rows, pitch, av6, T);
+    if (display == 4) slb_write_display4(norm, a_rows, b_rows, pitch, av6, T);
 
     if (read_from == NULL) break;
 
@@ -480,7 +487,7 @@ int slb_main(int argc, char **argv)
     if (quiet == 0) printf("# t_max = %0.20f\n", t_max);
   }
 
-  if (out != NULL && out != stdout && out != stderr) fclose(out);
+  slb_close_output();
   free(a_rows); free(b_rows);
   slb_solver_destroy(s);
   return EXIT_SUCCESS;

@@ -484,6 +484,7 @@ int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const 
 static int halo_double(slb_solver *s, float *buf_left, float *buf_right, int pack)
 {
   const int nrows = s->N + 1;
+  if (!buf_left && !buf_right) return 0;          /* a slab without neighbours */
   if (!s->spare_a || s->G < 4) return -1;
   slb_halo_seg seg[4];
   int k = 0;

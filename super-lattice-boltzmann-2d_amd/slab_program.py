@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""display=4 runs of the boltzmann_solver program over phi_y slabs, one process per GPU.
+
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 \\
+        super-lattice-boltzmann-2d_amd/slab_program.py display=4 E_dc=1 ... g-grid=8388608 o=out.txt
+
+Same name=value parameters (read by the same C parser) and the same display=4 record as
+the single-GPU program (reference: src/boltzmann_solver.c:74-401).  The lattices are
+bit-identical to a single-GPU run; the instantaneous sums and the norm are formed on
+rank 0 from the three rows they need, in the reference's order, so those columns are
+bit-identical too.  The period averages use av() over slabs (per-slab sums in double,
+all-reduced), which differs from the CPU's sequential float sums by their rounding noise.
+SLB_DIST_BACKEND=gloo stages the halo messages through host memory (rehearsals with
+several ranks on one GPU).
+"""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.basename(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(argv):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    slb = importlib.import_module(PKG)
+    drv = importlib.import_module(PKG + ".dist")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SLB_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    torch.zeros(1, device="cuda")
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend)
+
+    L = slb.lib()
+    # only rank 0 opens the o= file
+    args = [a for a in argv if rank == 0 or not a.startswith("o=")] + ([] if rank == 0 else ["o=stdout"])
+    cargs = (C.c_char_p * (len(args) + 2))(b"boltzmann_solver", *[a.encode() for a in args], None)
+    L.parse_cmd.argtypes, L.parse_cmd.restype = [C.c_int, C.POINTER(C.c_char_p)], None
+    L.parse_cmd(len(args) + 1, cargs)
+    if C.c_int.in_dll(L, "display").value != 4:
+        if rank == 0:
+            sys.stderr.write("ERROR: the slab program writes display=4 records only.\n")
+        return 1
+    L.slb_derive_and_load()
+    g = slb.get_global
+    omega, dt, E_omega = np.float32(g("host_omega")), np.float32(g("host_dt")), np.float32(g("host_E_omega"))
+    t_start = np.float32(g("t_start"))
+    T = np.float32(2 * 3.141592653589793115998 / np.float64(omega)) if omega > 0 else np.float32(0)
+    t_max = np.float32(t_start + T)
+    quiet = C.c_int.in_dll(L, "quiet").value
+    if rank == 0 and not quiet:
+        print("# t_max = %0.20f" % t_max, flush=True)
+
+    L.slb_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    L.slb_set_av_mode(slb.SLB_AV_TREE)
+    run = drv.SlabRun(slb, rank, world)
+    sol = run.eng.sol
+    run.tiptoe()
+    av_data = torch.zeros(6, dtype=torch.float32, device="cuda")
+
+    def averaged(t):
+        return E_omega > 0 and t >= t_start
+
+    while True:
+        t = np.float32(sol.s.t)                       # the engine's clock is the loop variable
+        if not t < t_max:
+            break
+        t2 = np.float32(t + dt)
+        if not averaged(t) and not averaged(t2) and t2 < t_max:
+            run.double_step()
+            continue
+        run.step_fused()
+        if averaged(t):
+            run.av(av_data, float(t))
+    t = np.float32(sol.s.t)
+
+    # the three rows the record's sums read, put together on rank 0
+    s = sol.s
+    torch.cuda.synchronize()
+    a01 = sol.rows(1 + s.current, 0, 2)
+    b1 = sol.rows(5 + s.current, 1, 1)
+    lo = s.G - 1 if rank == 0 else s.G
+    hi = s.G + s.W + 2 if rank == world - 1 else s.G + s.W
+    piece = (np.ascontiguousarray(a01[:, lo:hi]), np.ascontiguousarray(b1[:, lo:hi]))
+    pieces = [piece]
+    if world > 1:
+        pieces = [None] * world if rank == 0 else None
+        dist.gather_object(piece, pieces, dst=0)
+    rc = 0
+    if rank == 0:
+        M = g("host_M")
+        a_rows = np.ascontiguousarray(np.concatenate([p[0] for p in pieces], axis=1))
+        b_row = np.ascontiguousarray(np.concatenate([p[1] for p in pieces], axis=1))
+        assert a_rows.shape == (2, M + 3) and b_row.shape == (1, M + 3)
+        fp = C.c_void_p
+        L.slb_host_norm.argtypes, L.slb_host_norm.restype = [fp, C.c_int, C.c_float, C.c_float], C.c_float
+        L.slb_write_display4.argtypes = [C.c_float, fp, fp, C.c_int, fp, C.c_float]
+        L.slb_write_display4.restype = None
+        norm = L.slb_host_norm(a_rows.ctypes.data, M, g("host_dPhi"), g("host_alpha"))
+        av6 = av_data.cpu().numpy().copy()
+        L.slb_write_display4(norm, a_rows.ctypes.data, b_row.ctypes.data, M + 3, av6.ctypes.data, float(T))
+        L.slb_close_output.argtypes, L.slb_close_output.restype = [], None
+        L.slb_close_output()
+    run.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

@@ -93,3 +93,30 @@ def test_slabs_on_one_gpu(world, mode, tmp_path):
     scale = np.abs(av_ref[1:]).max()
     assert np.all(np.abs(parts[0]["av"][1:] - av_ref[1:]) <= 2e-5 * scale + 1e-9)
     ref.close()
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_slab_program_writes_the_single_gpu_record(world, tmp_path, solver_bin):
+    """slab_program.py (display=4 over slabs; here `world` processes on one GPU over gloo):
+    the instantaneous columns and the norm are the single-GPU program's to the last digit,
+    the period averages agree to the rounding noise of a float running sum."""
+    import subprocess
+    args = ["display=4", "E_dc=1", "E_omega=0.1", "omega=100", "mu=5", "alpha=1", "B=0.5", "PhiYmin=-4",
+            "PhiYmax=4", "dt=0.001", "n-harmonics=16", "g-grid=4001", "t-max=0.03", "quiet=1"]
+    one = subprocess.run([solver_bin] + args + ["o=one.txt"], cwd=tmp_path, capture_output=True, text=True,
+                         timeout=300, env={**os.environ, "SLB_AV": "tree"})
+    assert one.returncode == 0, one.stdout + one.stderr
+    script = os.path.join(sh.ROOT, sh.PKG, "slab_program.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(sh.free_port()), script] + args + ["o=slabs.txt"]
+    many = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600,
+                          env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
+    assert many.returncode == 0, many.stdout + many.stderr
+    a, b = (tmp_path / "one.txt").read_text().splitlines(), (tmp_path / "slabs.txt").read_text().splitlines()
+    assert len(a) == len(b) == 3 and a[:2] == b[:2]
+    ca, cb = a[2].split(), b[2].split()
+    exact = (0, 1, 2, 3, 4, 6, 7, 8)            # parameters, v_dr, NORM, v_y, m/m_x
+    assert [ca[i] for i in exact] == [cb[i] for i in exact]
+    for i in (5, 9, 10, 11, 12):                # A(omega), the three averages, Asin
+        x, y = float(ca[i]), float(cb[i])
+        assert abs(x - y) <= 2e-6 * max(abs(x), abs(y)) + 1e-9, (i, x, y)
