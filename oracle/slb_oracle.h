@@ -10,8 +10,10 @@
  * this path, and its CPU solver cannot be compiled in this image (it includes
  * <gsl/gsl_specfunc.h>; GSL is absent).  The only anchor is one display=4
  * output line of the compiled reference recorded when the reference was
- * surveyed (tests/golden/config1_display4_reference.json).  Beyond that line:
- * PARITY UNPINNED.  (Independent of the reference, the restatement is also held
+ * surveyed (tests/golden/config1_display4_reference.json), plus the iteration
+ * counts and a few four-digit observations recorded from it then
+ * (step_counts.json, config2_display77_reference_observations.json).  Beyond
+ * those: PARITY UNPINNED.  (Independent of the reference, the restatement is also held
  * to the model's analytic limit: with B = 0 and no a/c field it relaxes to the
  * Esaki-Tsu drift velocity 2E/(1+E^2) with unit norm -- a check of the physics,
  * not of the reference's bits.)

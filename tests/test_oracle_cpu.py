@@ -135,3 +135,81 @@ def test_esaki_tsu_limit_without_magnetic_field(oracle, tmp_path, E_dc):
     v_dr, norm, v_y = float(cols[4]), float(cols[6]), float(cols[7])
     assert abs(v_dr - 2 * E_dc / (1 + E_dc ** 2)) < 2e-4
     assert abs(norm - 1) < 1e-4 and abs(v_y) < 1e-6
+
+
+FIELDS = dict(N=8, M=61, B=0.05, omega=100.0)
+
+
+def test_oracle_matches_committed_field_fixtures(oracle):
+    """tests/golden/fields_N8_M61.npz and av_N8_M61.npz (written by make_fixtures.py from the
+    oracle itself: regression pins, not reference outputs) still come out bit for bit."""
+    fx = np.load(os.path.join(GOLDEN, "fields_N8_M61.npz"))
+    p = oracle.make_params(**FIELDS)
+    st = oracle.OracleState(p, threads=3)
+    try:
+        done = 0
+        for steps in (0, 1, 2, 10):
+            st.step(steps - done)
+            done = steps
+            assert [st.st.current, st.st.next, st.st.current_hs, st.st.next_hs] == list(fx[f"idx_{steps}"])
+            assert np.float32(st.st.t) == fx[f"t_{steps}"]
+            assert np.array_equal(st.array("a0").view(np.uint32), fx[f"eq_{steps}"].view(np.uint32))
+            for i in range(4):
+                for w in "ab":
+                    assert np.array_equal(st.array(w, i).view(np.uint32), fx[f"{w}{i}_{steps}"].view(np.uint32)), (w, i, steps)
+        av_fx = np.load(os.path.join(GOLDEN, "av_N8_M61.npz"))
+        cur = st.st.current
+        av = np.zeros(6, np.float32)
+        for k, t in enumerate(av_fx["times"], 1):
+            oracle.lib().orc_av(C.byref(p), st.array("a", cur), st.array("b", cur), av, np.float32(t))
+            assert np.array_equal(av.view(np.uint32), av_fx[f"after_{k}"].view(np.uint32)), k
+    finally:
+        st.close()
+
+
+def test_oracle_matches_committed_display77_trace(oracle, tmp_path):
+    args = ["display=77", "omega=100", "B=0.12", "n-harmonics=64", "g-grid=32768", "t-max=0.05", "E_dc=1",
+            "E_omega=0.1", "mu=5", "alpha=1", "PhiYmin=-4", "PhiYmax=4", "dt=0.001", "o=out.txt"]
+    oracle.run_cli(args, cwd=tmp_path)
+    assert (tmp_path / "out.txt").read_text() == open(os.path.join(GOLDEN, "display77_shrunken_config2.txt")).read()
+
+
+def test_step_counts_fixture_holds_the_counts_observed_on_the_reference(oracle):
+    """The loop runs while the float t < t_max: 16 281, 113 and 64 iterations are the counts the
+    reference itself was seen to take for these parameters; the oracle's clock gives the same."""
+    cases = json.load(open(os.path.join(GOLDEN, "step_counts.json")))
+    seen = {(c["dt"], c["t-max"], c["omega"]): c["iterations"] for c in cases}
+    assert seen[(0.001, 10.0, 1.0)] == 16281 and seen[(0.001, 0.05, 100.0)] == 113 and seen[(0.001, 0.001, 100.0)] == 64
+    for c in cases[1:]:
+        p = oracle.make_params(N=2, M=13, B=0.05, omega=c["omega"], dt=c["dt"], t_start=c["t-max"])
+        st = oracle.OracleState(p, threads=1)
+        n = 0
+        while st.st.t < st.st.t_max:
+            st.step(1)
+            n += 1
+        assert n == c["iterations"] and "%0.20f" % st.st.t_max == c["t_max"]
+        st.close()
+
+
+def _check_config2_observations(text):
+    obs = json.load(open(os.path.join(GOLDEN, "config2_display77_reference_observations.json")))
+    lines = text.splitlines()
+    assert len(lines) == obs["lines"]
+    rows = [l.split() for l in lines if not l.startswith("#")]
+    assert len(rows) == obs["records"]
+    v_dr = [float(r[4]) for r in rows]
+    norm = [float(r[6]) for r in rows]
+    t = [float(r[13]) for r in rows]
+    assert abs(v_dr[0] - obs["v_dr_first"]) < 5e-5 and abs(v_dr[-1] - obs["v_dr_last"]) < 5e-5
+    assert all(x < y for x, y in zip(v_dr, v_dr[1:]))                      # "rises"
+    assert abs(t[0] - obs["t_first"]) < 1e-6 and abs(t[-1] - obs["t_last"]) < 1e-6
+    assert round(min(norm), 6) == obs["norm_min"] and round(max(norm), 6) == obs["norm_max"]
+
+
+def test_oracle_reproduces_what_was_observed_on_the_reference_at_config2(oracle, tmp_path):
+    """Second anchor from the reference itself: the display=77 run of the config-2 shape was
+    seen to give 11 records with v_dr rising 0.0526 -> 0.5004 over t = 0.01 .. 0.11 and the
+    norm staying within 0.999876 .. 0.999879."""
+    obs = json.load(open(os.path.join(GOLDEN, "config2_display77_reference_observations.json")))
+    oracle.run_cli(obs["args"].split() + ["o=out.txt"], cwd=tmp_path, threads=8)
+    _check_config2_observations((tmp_path / "out.txt").read_text())

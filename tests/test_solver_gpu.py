@@ -329,3 +329,59 @@ def test_double_step_hands_out_the_rows_av_reads(slb, oracle, N, M, B, omega):
     finally:
         sol.close()
         orc.close()
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("form", ["sweeps", "fused", "double"])
+def test_engine_matches_committed_field_fixtures(slb, form):
+    """tests/golden/fields_N8_M61.npz (regression pins written from the CPU oracle): the GPU
+    engine reproduces the arrays after the tiptoe and after 1, 2, 10 iterations from the
+    files alone, in every step form (live state only after a double step)."""
+    fx = np.load(os.path.join(GOLDEN, "fields_N8_M61.npz"))
+    N, M = 8, 61
+    slb.configure(N=N, M=M, E_dc=1.0, E_omega=0.1, omega=100.0, mu=5.0, alpha=1.0, B=0.05,
+                  PhiYmin=-4.0, PhiYmax=4.0, dt=0.001)
+    sol = slb.Solver()
+    try:
+        sol.tiptoe()
+        done = 0
+        for steps in (0, 1, 2, 10):
+            while done < steps:
+                if form == "double" and steps - done >= 2:
+                    sol.double_step(); done += 2
+                elif form == "sweeps":
+                    sol.step(); done += 1
+                else:
+                    sol.step_fused(); done += 1
+            s = sol.s
+            assert [s.current, s.next, s.current_hs, s.next_hs] == list(fx[f"idx_{steps}"])
+            assert np.float32(s.t) == fx[f"t_{steps}"]
+            live = [("a0", 0, 0), ("a", s.current, 1 + s.current), ("b", s.current, 5 + s.current),
+                    ("a", s.current_hs, 1 + s.current_hs), ("b", s.current_hs, 5 + s.current_hs)]
+            every = [("a0", 0, 0)] + [("a", i, 1 + i) for i in range(4)] + [("b", i, 5 + i) for i in range(4)]
+            for w, i, arr in (live if form == "double" and steps >= 2 else every):
+                key = f"eq_{steps}" if w == "a0" else f"{w}{i}_{steps}"
+                assert np.array_equal(sol.rows(arr)[:, :M + 3].view(np.uint32), fx[key].view(np.uint32)), (key, form)
+    finally:
+        sol.close()
+
+
+def test_program_matches_committed_display77_trace(solver_bin, tmp_path):
+    args = ["display=77", "omega=100", "B=0.12", "n-harmonics=64", "g-grid=32768", "t-max=0.05"] + COMMON
+    g = subprocess.run([solver_bin] + args + ["o=out.txt"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert g.returncode == 0, g.stdout + g.stderr
+    assert (tmp_path / "out.txt").read_text() == open(os.path.join(GOLDEN, "display77_shrunken_config2.txt")).read()
+
+
+def test_program_config2_matches_what_was_observed_on_the_reference(solver_bin, tmp_path):
+    """The display=77 run of the full config-2 shape against the observations recorded from
+    the reference (tests/golden/config2_display77_reference_observations.json)."""
+    import json
+    from test_oracle_cpu import _check_config2_observations
+    obs = json.load(open(os.path.join(GOLDEN, "config2_display77_reference_observations.json")))
+    g = subprocess.run([solver_bin] + obs["args"].split() + ["o=out.txt", "quiet=1"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=600)
+    assert g.returncode == 0, g.stdout + g.stderr
+    _check_config2_observations((tmp_path / "out.txt").read_text())
