@@ -123,6 +123,11 @@ def main():
                 PhiYmin=-4.0, PhiYmax=4.0, dt=0.001)
     slb.configure(N=n_harm, M=g_grid, t_start=1.0, **phys)
     L = slb.lib()
+    if world > 1:
+        # not the legacy null stream: its implicit synchronisation with other streams would
+        # serialise the halo messages with the interior launches (measured: 1.26 ms instead
+        # of 1.18 ms per double step with RCCL in the loop)
+        torch.cuda.set_stream(torch.cuda.Stream())
     L.slb_set_stream(torch.cuda.current_stream().cuda_stream)
     L.slb_set_tuning(args.variant, args.n_chunk, args.block)
 

@@ -23,15 +23,37 @@ class Loopback(drv.SlabRun):
         return [], []
 
 
+class NcclSelf(drv.SlabRun):
+    """The messages go through torch.distributed + RCCL for real, addressed to this rank
+    itself (one process, backend nccl): the library's launch and host costs without xGMI."""
+    def _post(self, send, recv):
+        import torch.distributed as dist
+        ops = []
+        for side, peer in ((0, self.left), (1, self.right)):
+            if peer is not None:
+                ops.append(dist.P2POp(dist.isend, send[side], 0))
+                ops.append(dist.P2POp(dist.irecv, recv[side], 0))
+        return (dist.batch_isend_irecv(ops) if ops else []), []
+
+
 def main():
+    nccl_self = "--nccl-self" in sys.argv
+    if nccl_self:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     world, per_gpu, N = 3, 1 << 20, 128
     M = per_gpu * world
     torch.zeros(1, device="cuda")
     slb.configure(N=N, M=M, E_dc=1.0, E_omega=0.1, omega=100.0, mu=5.0, alpha=1.0, B=4000.0 / M,
                   PhiYmin=-4.0, PhiYmax=4.0, dt=0.001, t_start=1.0)
+    if "--own-stream" in sys.argv:              # not the legacy null stream
+        torch.cuda.set_stream(torch.cuda.Stream())
     slb.lib().slb_set_stream(torch.cuda.current_stream().cuda_stream)
     for rank, label in ((1, "middle slab (two neighbours)"), (0, "first slab (one neighbour)")):
-        run = Loopback(slb, rank, world)
+        run = (NcclSelf if nccl_self else Loopback)(slb, rank, world)
         run.tiptoe()
         for _ in range(5):
             run.double_step()

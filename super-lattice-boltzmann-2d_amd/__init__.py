@@ -120,6 +120,8 @@ def lib():
         L.slb_solver_step.argtypes, L.slb_solver_step.restype = [C.POINTER(SolverStruct)], None
         L.slb_solver_step_fused.argtypes, L.slb_solver_step_fused.restype = [C.POINTER(SolverStruct)], None
         L.slb_solver_double_step.argtypes, L.slb_solver_double_step.restype = [C.POINTER(SolverStruct)], None
+        L.slb_solver_prepare_double_step.argtypes = [C.POINTER(SolverStruct)]
+        L.slb_solver_prepare_double_step.restype = None
         L.slb_solver_double_step_rows.argtypes = [C.POINTER(SolverStruct), fp, fp]
         L.slb_solver_double_step_rows.restype = None
         L.slb_av_sums_exact.argtypes, L.slb_av_sums_exact.restype = [C.POINTER(Slab), fp, fp, fp], i
@@ -292,6 +294,9 @@ class Solver:
         rc = lib().slb_solver_halo_unpack_double(self._p, left_ptr, right_ptr)
         if rc:
             raise RuntimeError(f"slb_solver_halo_unpack_double -> {rc}")
+
+    def prepare_double_step(self):
+        lib().slb_solver_prepare_double_step(self._p)
 
     def double_step_rows(self, rows_first_ptr, rows_second_ptr):
         """double_step() that also writes a rows 0, 1 and b row 1 of both new main lattices

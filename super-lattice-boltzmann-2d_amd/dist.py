@@ -22,8 +22,14 @@ Three step forms, bit-identical to each other and to a single-domain run:
 * ``double_step()`` -- two loop iterations (four sweeps) in one launch per column
   range.  A slab recomputes the three earlier sweeps up to three columns into
   its ghost zone; afterwards the new main lattice (3 columns) and the new
-  half-step lattice (4 columns) travel, ONE exchange per TWO steps:
-      edge ranges -> pack -> send/recv -> interior range -> wait -> unpack
+  half-step lattice (4 columns) travel, ONE message per neighbour per TWO steps.
+  On the GPU the two kinds of work go to two streams that run side by side:
+      side stream:  edge ranges -> pack -> send/recv -> wait -> unpack
+      main stream:  interior range
+  Each waits for the other's PREVIOUS double step only (the interior reads what the
+  last edge ranges wrote and the other way round; this step's results go to the
+  spare arrays), so the interior launches follow each other without a gap and
+  everything about the halo hides behind them.
 
 Either way the few-KB messages travel while the interior is being updated.
 After every step form all G ghost columns of both current lattices are valid,
@@ -121,6 +127,16 @@ class SlabRun:
         self.send2 = [self.eng.new_buffer(7), self.eng.new_buffer(7)]
         self.recv2 = [self.eng.new_buffer(7), self.eng.new_buffer(7)]
         self.cpu_staging = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        # second stream for the halo work of double steps (HIP engine with neighbours only)
+        self.side = None
+        if isinstance(self.eng, HipEngine) and (self.left is not None or self.right is not None):
+            self.main = torch.cuda.current_stream()
+            # default priority: a high-priority side stream was seen to stall runs in which
+            # several processes share one GPU (its event waits then starve the main streams)
+            self.side = torch.cuda.Stream()
+            self.ev_main = torch.cuda.Event()       # the last interior launch
+            self.ev_side = torch.cuda.Event()       # the last halo chain
+            self.side_busy = False
 
     # -- transport: one message per neighbour, all of them in one batch ---------
     def _post(self, send, recv):
@@ -208,6 +224,7 @@ class SlabRun:
         self.exchange(0, 4)
 
     def step(self):
+        self.join()
         c = self.eng.cosines()
         self._sweep(0, 1, 1, c[0], c[1])   # main lattice: writes a/b[next], ships 1 edge column
         self._sweep(1, 2, 1, c[2], c[3])   # half-step lattice: writes a/b[next_hs]
@@ -217,6 +234,7 @@ class SlabRun:
 
     # -- one-launch form -------------------------------------------------------
     def step_fused(self):
+        self.join()
         e = self.eng
         c = e.cosines()
         first, last_owned = e.G, e.G + e.W - 1
@@ -236,6 +254,8 @@ class SlabRun:
 
     # -- two iterations per launch ----------------------------------------------
     def double_step(self):
+        if self.side is not None:
+            return self._double_step_two_streams()
         e = self.eng
         c = e.cosines2()
         first, last_owned = e.G, e.G + e.W - 1
@@ -254,12 +274,68 @@ class SlabRun:
         self._double_halo(self.recv2, pack=False)
         e.double_step_finish()                       # the spares become the current lattices
 
+    def _on_side(self):
+        """Context: launches of the engine and of torch.distributed go to the side stream."""
+        run = self
+
+        class _Ctx:
+            def __enter__(self):
+                self.ctx = torch.cuda.stream(run.side)
+                self.ctx.__enter__()
+                run.eng.slb.lib().slb_set_stream(run.side.cuda_stream)
+
+            def __exit__(self, *exc):
+                run.eng.slb.lib().slb_set_stream(run.main.cuda_stream)
+                return self.ctx.__exit__(*exc)
+        return _Ctx()
+
+    def _double_step_two_streams(self):
+        e = self.eng
+        c = e.cosines2()
+        first, last_owned = e.G, e.G + e.W - 1
+        lo = first + 4 if self.left is not None else first
+        hi = last_owned - 4 if self.right is not None else last_owned
+        e.slb.lib().slb_set_stream(self.main.cuda_stream)
+        e.sol.prepare_double_step()                  # spare arrays, if stale, on the main stream
+        # halo chain: reads what the last interior launch wrote, writes the spare arrays'
+        # edge and ghost columns (which that launch read)
+        self.side.wait_event(self.ev_main) if self.side_busy else self.side.wait_stream(self.main)
+        with self._on_side():
+            if self.left is not None:
+                e.double_step_range(first, first + 3, c)
+            if self.right is not None:
+                e.double_step_range(last_owned - 3, last_owned, c)
+            self._double_halo(self.send2, pack=True)
+            posted = self._post(self.send2, self.recv2)
+        # interior: reads what the last halo chain wrote, writes the spare arrays' interior
+        # (which that chain read)
+        if self.side_busy:
+            self.main.wait_event(self.ev_side)
+        e.double_step_range(lo, hi, c)
+        self.ev_main = torch.cuda.Event()
+        self.ev_main.record(self.main)
+        with self._on_side():
+            self._complete(posted)
+            self._double_halo(self.recv2, pack=False)
+            self.ev_side = torch.cuda.Event()
+            self.ev_side.record(self.side)
+        self.side_busy = True
+        e.double_step_finish()                       # the spares become the current lattices
+
+    def join(self):
+        """Make the main stream wait for the side stream's halo work (before anything but
+        another double step touches the lattices)."""
+        if self.side is not None and self.side_busy:
+            self.main.wait_event(self.ev_side)
+            self.side_busy = False
+
     # -- harmonic reductions over all slabs ---------------------------------------
     def av(self, av_data, t):
         """The reference's av() for the lattice the last step produced: every slab sums
         its own columns (wave64 tree, double), the three sums are added across slabs,
         and every rank applies the same update to its copy of av_data (6 floats on
         the device).  `t` is the loop time of the step just taken."""
+        self.join()
         sums = self.eng.av_partial()
         if self.world > 1:
             if self.cpu_staging and sums.is_cuda:
@@ -271,4 +347,7 @@ class SlabRun:
         self.eng.av_update(sums, av_data, t)
 
     def close(self):
+        self.join()
+        if self.side is not None:
+            torch.cuda.synchronize()
         self.eng.close()

@@ -97,6 +97,8 @@ void slb_solver_step_fused_range(slb_solver *s, int j2_first, int j2_last, const
  * call allocates four spare arrays.  Same state afterwards as two
  * slb_solver_step() calls, bit for bit (ping-pong indices included). */
 void slb_solver_double_step(slb_solver *s);
+/* refresh the spare arrays now (current stream) if the next double step would need to */
+void slb_solver_prepare_double_step(slb_solver *s);
 /* the same, also writing the rows av() reads of both new main lattices into two
  * [3][pitch] device buffers (a row 0, a row 1, b row 1) */
 void slb_solver_double_step_rows(slb_solver *s, float *rows_first, float *rows_second);

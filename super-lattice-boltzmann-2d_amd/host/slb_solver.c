@@ -276,6 +276,14 @@ static void sync_spares(slb_solver *s)
 static void double_step_range_rows(slb_solver *s, int j_first, int j_last, const float c[8],
                                    float *rows_first, float *rows_second);
 
+/* Bring the spare arrays up to date now, on the current stream, if the next double step
+ * would have to (first use, or single steps since the last one): a caller that spreads
+ * the ranges of a double step over several streams does this first. */
+void slb_solver_prepare_double_step(slb_solver *s)
+{
+  if (!s->spare_a || s->spare_of != s->current || s->spare_of_hs != s->current_hs) sync_spares(s);
+}
+
 void slb_solver_double_step_range(slb_solver *s, int j_first, int j_last, const float c[8])
 {
   double_step_range_rows(s, j_first, j_last, c, NULL, NULL);

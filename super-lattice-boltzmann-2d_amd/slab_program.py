@@ -63,6 +63,8 @@ def main(argv):
     if rank == 0 and not quiet:
         print("# t_max = %0.20f" % t_max, flush=True)
 
+    if world > 1:
+        torch.cuda.set_stream(torch.cuda.Stream())    # not the legacy null stream (implicit synchronisation)
     L.slb_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
     L.slb_set_av_mode(slb.SLB_AV_TREE)
     run = drv.SlabRun(slb, rank, world)
