@@ -14,6 +14,10 @@
  * per call (one small workspace is allocated on first use of the reductions).
  * Launches are asynchronous on the stream set by slb_set_stream() (default: the
  * null stream, as in the reference).
+ *
+ * Like the reference's boundary the library is meant for ONE host thread per
+ * process and one GPU per process: load_data(), slb_set_stream(), slb_set_av_mode()
+ * and slb_set_tuning() set process-wide state that the following launches read.
  */
 #ifndef SLB_ABI_H
 #define SLB_ABI_H
