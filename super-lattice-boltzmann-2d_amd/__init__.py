@@ -128,6 +128,8 @@ def lib():
         L.slb_av_update_exact.argtypes, L.slb_av_update_exact.restype = [fp, fp, f], i
         L.slb_solver_double_step_range.argtypes = [C.POINTER(SolverStruct), i, i, C.POINTER(C.c_float * 8)]
         L.slb_solver_double_step_range.restype = None
+        L.slb_solver_double_step_range_rows.argtypes = [C.POINTER(SolverStruct), i, i, C.POINTER(C.c_float * 8), fp, fp]
+        L.slb_solver_double_step_range_rows.restype = None
         L.slb_solver_double_step_finish.argtypes = [C.POINTER(SolverStruct)]
         L.slb_solver_double_step_finish.restype = None
         L.slb_solver_multi_step.argtypes, L.slb_solver_multi_step.restype = [C.POINTER(SolverStruct), i], None
@@ -236,9 +238,14 @@ class Solver:
     def multi_step_finish(self, S):
         lib().slb_solver_multi_step_finish(self._p, S)
 
-    def double_step_range(self, j_first, j_last, cosines8):
+    def double_step_range(self, j_first, j_last, cosines8, rows=None):
+        """rows: optional pair of device pointers to [3][pitch] buffers that receive the rows
+        av() reads of the main lattices after the first and the second iteration."""
         c = (C.c_float * 8)(*cosines8)
-        lib().slb_solver_double_step_range(self._p, j_first, j_last, C.byref(c))
+        if rows is None:
+            lib().slb_solver_double_step_range(self._p, j_first, j_last, C.byref(c))
+        else:
+            lib().slb_solver_double_step_range_rows(self._p, j_first, j_last, C.byref(c), rows[0], rows[1])
 
     def double_step_finish(self):
         lib().slb_solver_double_step_finish(self._p)

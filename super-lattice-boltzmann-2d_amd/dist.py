@@ -37,6 +37,8 @@ so the forms can be mixed freely.
 All arithmetic stays in the engine (the HIP kernels); this file only orders
 launches and moves 2*ncols*(N+1) floats per side.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -71,8 +73,21 @@ class HipEngine:
     def cosines2(self):
         return self.slb.step2_cosines(self.sol.s.t)
 
-    def double_step_range(self, j_first, j_last, cosines8):
-        self.sol.double_step_range(j_first, j_last, cosines8)
+    def double_step_range(self, j_first, j_last, cosines8, rows=None):
+        self.sol.double_step_range(j_first, j_last, cosines8,
+                                   None if rows is None else (rows[0].data_ptr(), rows[1].data_ptr()))
+
+    def new_rows(self):
+        """A [3][pitch] buffer for the rows av() reads (a rows 0, 1 and b row 1)."""
+        return torch.zeros((3, self.sol.s.pitch), dtype=torch.float32, device=self.device)
+
+    def av_partial_rows(self, rows):
+        sums = torch.zeros(4, dtype=torch.float64, device=self.device)
+        rc = self.slb.lib().slb_av_partial(C.byref(self.sol.s.av_slab), rows.data_ptr(),
+                                           rows.data_ptr() + 4 * self.sol.s.pitch, sums.data_ptr())
+        if rc:
+            raise RuntimeError(f"slb_av_partial -> {rc}")
+        return sums
 
     def double_step_finish(self):
         self.sol.double_step_finish()
@@ -253,23 +268,27 @@ class SlabRun:
         self._refresh_ghosts()
 
     # -- two iterations per launch ----------------------------------------------
-    def double_step(self):
+    def double_step(self, rows=None):
+        """rows: optional pair of buffers from engine.new_rows(); they receive the rows av()
+        reads of the main lattice after the first and after the second iteration (own
+        columns), for av_rows()."""
+        kw = {} if rows is None else {"rows": rows}
         if self.side is not None:
-            return self._double_step_two_streams()
+            return self._double_step_two_streams(kw)
         e = self.eng
         c = e.cosines2()
         first, last_owned = e.G, e.G + e.W - 1
         lo, hi = first, last_owned
         if self.left is not None:
-            e.double_step_range(first, first + 3, c)
+            e.double_step_range(first, first + 3, c, **kw)
             lo = first + 4
         if self.right is not None:
-            e.double_step_range(last_owned - 3, last_owned, c)
+            e.double_step_range(last_owned - 3, last_owned, c, **kw)
             hi = last_owned - 4
         # the edge columns of both new lattices sit in the spare arrays
         self._double_halo(self.send2, pack=True)
         posted = self._post(self.send2, self.recv2)
-        e.double_step_range(lo, hi, c)
+        e.double_step_range(lo, hi, c, **kw)
         self._complete(posted)
         self._double_halo(self.recv2, pack=False)
         e.double_step_finish()                       # the spares become the current lattices
@@ -289,7 +308,7 @@ class SlabRun:
                 return self.ctx.__exit__(*exc)
         return _Ctx()
 
-    def _double_step_two_streams(self):
+    def _double_step_two_streams(self, kw):
         e = self.eng
         c = e.cosines2()
         first, last_owned = e.G, e.G + e.W - 1
@@ -302,16 +321,16 @@ class SlabRun:
         self.side.wait_event(self.ev_main) if self.side_busy else self.side.wait_stream(self.main)
         with self._on_side():
             if self.left is not None:
-                e.double_step_range(first, first + 3, c)
+                e.double_step_range(first, first + 3, c, **kw)
             if self.right is not None:
-                e.double_step_range(last_owned - 3, last_owned, c)
+                e.double_step_range(last_owned - 3, last_owned, c, **kw)
             self._double_halo(self.send2, pack=True)
             posted = self._post(self.send2, self.recv2)
         # interior: reads what the last halo chain wrote, writes the spare arrays' interior
         # (which that chain read)
         if self.side_busy:
             self.main.wait_event(self.ev_side)
-        e.double_step_range(lo, hi, c)
+        e.double_step_range(lo, hi, c, **kw)
         self.ev_main = torch.cuda.Event()
         self.ev_main.record(self.main)
         with self._on_side():
@@ -337,6 +356,20 @@ class SlabRun:
         the device).  `t` is the loop time of the step just taken."""
         self.join()
         sums = self.eng.av_partial()
+        if self.world > 1:
+            if self.cpu_staging and sums.is_cuda:
+                host = sums.cpu()
+                dist.all_reduce(host, group=self.group)
+                sums.copy_(host)
+            else:
+                dist.all_reduce(sums, group=self.group)
+        self.eng.av_update(sums, av_data, t)
+
+    def av_rows(self, rows, av_data, t):
+        """av() from a rows buffer that a double_step(rows=...) filled; t = the loop time of
+        the iteration the buffer belongs to."""
+        self.join()
+        sums = self.eng.av_partial_rows(rows)
         if self.world > 1:
             if self.cpu_staging and sums.is_cuda:
                 host = sums.cpu()

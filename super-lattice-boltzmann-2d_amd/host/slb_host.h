@@ -102,6 +102,8 @@ void slb_solver_prepare_double_step(slb_solver *s);
 /* the same, also writing the rows av() reads of both new main lattices into two
  * [3][pitch] device buffers (a row 0, a row 1, b row 1) */
 void slb_solver_double_step_rows(slb_solver *s, float *rows_first, float *rows_second);
+void slb_solver_double_step_range_rows(slb_solver *s, int j_first, int j_last, const float c[8],
+                                       float *rows_first, float *rows_second);
 /* the same in pieces, for drivers that overlap a halo exchange: the launch for
  * the last sweep's columns j_first..j_last (results go to the spare arrays),
  * then the hand-over of the spares and the time advance */

@@ -273,9 +273,6 @@ static void sync_spares(slb_solver *s)
  * zone next to a neighbour, not into a global boundary column.  Results go to
  * the spare arrays; slb_solver_double_step_finish() makes them current.
  * c[0..3] = cosines of the first iteration, c[4..7] of the second. */
-static void double_step_range_rows(slb_solver *s, int j_first, int j_last, const float c[8],
-                                   float *rows_first, float *rows_second);
-
 /* Bring the spare arrays up to date now, on the current stream, if the next double step
  * would have to (first use, or single steps since the last one): a caller that spreads
  * the ranges of a double step over several streams does this first. */
@@ -286,11 +283,13 @@ void slb_solver_prepare_double_step(slb_solver *s)
 
 void slb_solver_double_step_range(slb_solver *s, int j_first, int j_last, const float c[8])
 {
-  double_step_range_rows(s, j_first, j_last, c, NULL, NULL);
+  slb_solver_double_step_range_rows(s, j_first, j_last, c, NULL, NULL);
 }
 
-static void double_step_range_rows(slb_solver *s, int j_first, int j_last, const float c[8],
-                                   float *rows_first, float *rows_second)
+/* the same, also writing the rows av() reads of both new main lattices (see
+ * slb_solver_double_step_rows) at the columns this range forms */
+void slb_solver_double_step_range_rows(slb_solver *s, int j_first, int j_last, const float c[8],
+                                       float *rows_first, float *rows_second)
 {
   if (!s->spare_a || s->spare_of != s->current || s->spare_of_hs != s->current_hs) sync_spares(s);
   const int G = s->G, first = s->rank == 0, last = s->rank == s->nranks - 1;
@@ -352,7 +351,7 @@ void slb_solver_double_step_rows(slb_solver *s, float *rows_first, float *rows_s
 {
   float c[8];
   slb_step2_cosines(s->t, c);
-  double_step_range_rows(s, s->half_slab.j_first, s->half_slab.j_last, c, rows_first, rows_second);
+  slb_solver_double_step_range_rows(s, s->half_slab.j_first, s->half_slab.j_last, c, rows_first, rows_second);
   slb_solver_double_step_finish(s);
 }
 

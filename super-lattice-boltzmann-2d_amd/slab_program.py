@@ -75,13 +75,20 @@ def main(argv):
     def averaged(t):
         return E_omega > 0 and t >= t_start
 
+    rows = (run.eng.new_rows(), run.eng.new_rows())
     while True:
         t = np.float32(sol.s.t)                       # the engine's clock is the loop variable
         if not t < t_max:
             break
         t2 = np.float32(t + dt)
-        if not averaged(t) and not averaged(t2) and t2 < t_max:
-            run.double_step()
+        if t2 < t_max and averaged(t) == averaged(t2):
+            if averaged(t):
+                # two iterations per launch; the launch also hands out the rows av() reads of both
+                run.double_step(rows=rows)
+                run.av_rows(rows[0], av_data, float(t))
+                run.av_rows(rows[1], av_data, float(t2))
+            else:
+                run.double_step()
             continue
         run.step_fused()
         if averaged(t):
