@@ -1,7 +1,10 @@
 // slb_kernels.hip -- gfx950 (MI355X) kernels and the C boundary of libslb2d.so.
 //
-// What runs here: the two lattice sweeps of the Boltzmann stepping loop and the
-// harmonic reductions, behind the entry points declared in include/slb_abi.h.
+// What runs here: the two lattice sweeps of the Boltzmann stepping loop (one per
+// launch, both of a time step in one launch, two or more time steps in one launch),
+// the harmonic reductions (exact-order float sums evaluated in parallel, or a tree),
+// the display=8 frame sums and the halo movers for phi_y slabs, behind the entry
+// points declared in include/slb_abi.h.
 // Arithmetic is IEEE binary32, one rounding per operation, in the association
 // order of the reference CPU sweeps (reference: src/boltzmann_c_solver.c:363-378),
 // so that fields are bit-identical to the CPU solver.  This file must be compiled
