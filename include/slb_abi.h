@@ -280,7 +280,9 @@ void *slb_get_stream(void);
  *   accesses for data touched once (the default where rows are 16-byte aligned).
  * variant, slb_step_fused: 6 = plain accesses (default), 7 = nontemporal.
  * variant, slb_step_fused2: 21 / 23 (default) / 25 = register budget of 2 / 3 / 4
- *   waves per SIMD.  slb_seq_sum: 41..47 = other workgroup shapes.
+ *   waves per SIMD.  slb_step_multi: 32 / 33 / 34 = two columns per lane instead
+ *   of four, with a register budget of 2 / 3 / 4 waves per SIMD.
+ *   slb_seq_sum: 41..47 = other workgroup shapes.
  * n_chunk = rows per workgroup in n (0: by lattice width), block = threads (0: 256). */
 void slb_set_tuning(int variant, int n_chunk, int block);
 

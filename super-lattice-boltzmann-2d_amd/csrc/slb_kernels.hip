@@ -885,11 +885,22 @@ struct MultiArgs {
   int jf[Q], jl[Q];                          // columns each stage produces
 };
 
-template <int S, int MINW, bool DIAG = false>
+// V = columns per lane (4: 16-byte accesses; 2: half the registers per lane, twice the waves)
+template <int V>
+__device__ __forceinline__ void widen_v(const float (&own)[V], float (&e)[V + 2])
+{
+  e[0] = from_left_lane(own[V - 1]);
+#pragma unroll
+  for (int k = 0; k < V; k++) e[k + 1] = own[k];
+  e[V + 1] = from_right_lane(own[0]);
+}
+
+template <int S, int V, int MINW, bool DIAG = false>
 __global__ void __launch_bounds__(256, MINW)
 multi_step_kernel(const MultiArgs<S> p)
 {
-  constexpr int V = 4, Q = 2 * S, H = (Q - 1 + 3) / 4, INNER = 64 - 2 * H;
+  static_assert(V == 2 || V == 4, "two or four columns per lane");
+  constexpr int Q = 2 * S, H = (Q - 1 + V - 1) / V, INNER = 64 - 2 * H;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int jj   = p.jj0 + (wave * INNER + lane - H) * V;       // first own column (may be < 0)
@@ -907,8 +918,8 @@ multi_step_kernel(const MultiArgs<S> p)
   const int r_end = n1 + Q - 2;                                 // last stage forms row n1-1 then
 
   float bphi[V];
-  unsigned ok = 0;          // bit q*4+k: stage q produces column k (stages 0..Q-2)
-  unsigned wr = 0;          // bit k: stage Q-2 stores column k; bit 4+k: stage Q-1 stores it
+  unsigned ok = 0;          // bit q*V+k: stage q produces column k (stages 0..Q-2)
+  unsigned wr = 0;          // bit k: stage Q-2 stores column k; bit V+k: stage Q-1 stores it
   unsigned need = 0;        // bit q: this lane must fetch never-written cells for stage q
 #pragma unroll
   for (int k = 0; k < V; k++) {
@@ -918,12 +929,12 @@ multi_step_kernel(const MultiArgs<S> p)
 #pragma unroll
     for (int q = 0; q < Q - 1; q++) {
       const bool okq = c >= p.jf[q] && c <= p.jl[q];
-      if (okq) ok |= 1u << (q * 4 + k);
+      if (okq) ok |= 1u << (q * V + k);
       // a column the next stage reads at m+-1 that this stage does not produce keeps its old value
       if (!okq && in_row && c >= p.jf[q + 1] - 1 && c <= p.jl[q + 1] + 1) need |= 1u << q;
     }
     if (interior && c >= p.jf[Q - 2] && c <= p.jl[Q - 2]) wr |= 1u << k;
-    if (interior && c >= p.jf[Q - 1] && c <= p.jl[Q - 1]) wr |= 1u << (4 + k);
+    if (interior && c >= p.jf[Q - 1] && c <= p.jl[Q - 1]) wr |= 1u << (V + k);
   }
   if (jj != jcl) need = 0;
   float sc[2 * Q];
@@ -932,12 +943,22 @@ multi_step_kernel(const MultiArgs<S> p)
 
   const size_t P = (size_t)p.pitch;
   auto load4 = [&](const float *base, size_t row, float (&v)[V]) {
-    const float4 x = *reinterpret_cast<const float4 *>(base + row + j);
-    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    if constexpr (V == 4) {
+      const float4 x = *reinterpret_cast<const float4 *>(base + row + j);
+      v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    } else {
+      const float2 x = *reinterpret_cast<const float2 *>(base + row + j);
+      v[0] = x.x; v[1] = x.y;
+    }
   };
+  auto store_all = [&](float *base, size_t row, const float (&v)[V]) {
+    if constexpr (V == 4) *reinterpret_cast<float4 *>(base + row + j) = make_float4(v[0], v[1], v[2], v[3]);
+    else                  *reinterpret_cast<float2 *>(base + row + j) = make_float2(v[0], v[1]);
+  };
+  constexpr unsigned ALL = (1u << V) - 1u;
   auto diffs = [&](const float (&own)[V], float (&d)[V]) {
-    float e[6];
-    widen(own, e);
+    float e[V + 2];
+    widen_v<V>(own, e);
 #pragma unroll
     for (int k = 0; k < V; k++) d[k] = e[k + 2] - e[k];
   };
@@ -963,10 +984,10 @@ multi_step_kernel(const MultiArgs<S> p)
       const int n = r - q;
       const int lo_q = n0 > Q - 1 - q ? n0 - (Q - 1 - q) : 0;
       if (n >= lo_q && n < p.N) {
-        float ea[6], eb[6], dla[V], dlb[V];
+        float ea[V + 2], eb[V + 2], dla[V], dlb[V];
         // stencil: row n+1 (this iteration) with its m+-1 neighbours, row n-1 as differences
-        if (q == 0) { widen(upA0, ea); widen(upB0, eb); diffs(hA[1], dla); diffs(hB[1], dlb); }
-        else        { widen(nA[q - 1], ea); widen(nB[q - 1], eb); diffs(oA[q - 1][1], dla); diffs(oB[q - 1][1], dlb); }
+        if (q == 0) { widen_v<V>(upA0, ea); widen_v<V>(upB0, eb); diffs(hA[1], dla); diffs(hB[1], dlb); }
+        else        { widen_v<V>(nA[q - 1], ea); widen_v<V>(nB[q - 1], eb); diffs(oA[q - 1][1], dla); diffs(oB[q - 1][1], dlb); }
         const float fn = (float)n;
 #pragma unroll
         for (int k = 0; k < V; k++) {
@@ -980,10 +1001,10 @@ multi_step_kernel(const MultiArgs<S> p)
         const size_t row = (size_t)n * P;
         if (q >= Q - 2 && n >= n0 && n < n1) {
           float *da = q == Q - 2 ? p.a_o : p.a_ho, *db = q == Q - 2 ? p.b_o : p.b_ho;
-          const unsigned w = q == Q - 2 ? (wr & 0xfu) : (wr >> 4);
-          if (w == 0xfu) {
-            st4<false>(da + row, j, nA[q]);
-            if (n > 0) st4<false>(db + row, j, nB[q]);
+          const unsigned w = q == Q - 2 ? (wr & ALL) : (wr >> V);
+          if (w == ALL) {
+            store_all(da, row, nA[q]);
+            if (n > 0) store_all(db, row, nB[q]);
           } else {
 #pragma unroll
             for (int k = 0; k < V; k++) {
@@ -1000,7 +1021,7 @@ multi_step_kernel(const MultiArgs<S> p)
             load4(p.pers_a[q], row, xa); load4(p.pers_b[q], row, xb);
 #pragma unroll
             for (int k = 0; k < V; k++)
-              if (!(ok & (1u << (q * 4 + k)))) { nA[q][k] = xa[k]; nB[q][k] = xb[k]; }
+              if (!(ok & (1u << (q * V + k)))) { nA[q][k] = xa[k]; nB[q][k] = xb[k]; }
           }
         }
       } else if (q < Q - 1 && n == p.N) {
@@ -1569,11 +1590,11 @@ int launch_fused2(Fused2Args &args, int block)
   return (int)hipGetLastError();
 }
 
-template <int S, int MINW, bool DIAG = false>
+template <int S, int V, int MINW, bool DIAG = false>
 int launch_multi(const slb_multi_geom *g, const float *a0, const float *const *in, const float *const *pers_a,
                  const float *const *pers_b, float *const *out, const float *cosines, int block, int n_chunk)
 {
-  constexpr int Q = 2 * S, H = (Q - 1 + 3) / 4, INNER = 64 - 2 * H;
+  constexpr int Q = 2 * S, H = (Q - 1 + V - 1) / V, INNER = 64 - 2 * H;
   MultiArgs<S> s;
   s.a0 = a0; s.a_c = in[0]; s.b_c = in[1]; s.a_h = in[2]; s.b_h = in[3];
   for (int q = 0; q < Q - 1; q++) { s.pers_a[q] = pers_a[q]; s.pers_b[q] = pers_b[q]; }
@@ -1588,13 +1609,13 @@ int launch_multi(const slb_multi_geom *g, const float *a0, const float *const *i
     s.jf[q] = g->j_first[q]; s.jl[q] = g->j_last[q];
     lo = s.jf[q] < lo ? s.jf[q] : lo; hi = s.jl[q] > hi ? s.jl[q] : hi;
   }
-  s.jj0 = lo / 4 * 4;
+  s.jj0 = lo / V * V;
   s.n_chunk = n_chunk > s.N ? s.N : n_chunk;
-  const int per_wave = INNER * 4;
+  const int per_wave = INNER * V;
   const int waves = (hi + 1 - s.jj0 + per_wave - 1) / per_wave;
   const int wpb = block / 64;
   dim3 grid((waves + wpb - 1) / wpb, (s.N + s.n_chunk - 1) / s.n_chunk);
-  hipLaunchKernelGGL((multi_step_kernel<S, MINW, DIAG>), grid, dim3(block), 0, g_stream, s);
+  hipLaunchKernelGGL((multi_step_kernel<S, V, MINW, DIAG>), grid, dim3(block), 0, g_stream, s);
   return (int)hipGetLastError();
 }
 
@@ -1841,21 +1862,29 @@ int slb_step_multi(const slb_multi_geom *g, const float *a0, const float *const 
   const int block = g_block > 0 ? g_block : 256;
   if (block % 64 != 0 || block > 256) { fprintf(stderr, "slb_step_multi: block must be 64, 128, 192 or 256\n"); return -1; }
   const int n_chunk = g_n_chunk > 0 ? g_n_chunk : 64;
-  // waves per SIMD the register allocator is held to: measured best per S on MI355X
+  // waves per SIMD the register allocator is held to: measured best per S on MI355X.
+  // tuning variants 32..34: two columns per lane (half the registers, twice the waves)
+  // with a budget of 2, 3, 4 waves per SIMD
+  const int v = g_variant;
+  if (v >= 32 && v <= 34) {
+    switch (g->steps * 10 + (v - 32)) {
+      case 20: return launch_multi<2, 2, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 21: return launch_multi<2, 2, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 22: return launch_multi<2, 2, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 30: return launch_multi<3, 2, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 31: return launch_multi<3, 2, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 32: return launch_multi<3, 2, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 40: return launch_multi<4, 2, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 41: return launch_multi<4, 2, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 42: return launch_multi<4, 2, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      default: break;
+    }
+  }
   switch (g->steps) {
-    case 1: return launch_multi<1, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
-#ifdef SLB_TIMING_VARIANTS
-#define v g_variant
-    case 2: return v == 97 ? launch_multi<2, 3, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
-                           : launch_multi<2, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
-    case 3: return v == 97 ? launch_multi<3, 2, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk)
-                           : launch_multi<3, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
-#undef v
-#else
-    case 2: return launch_multi<2, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
-    case 3: return launch_multi<3, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
-#endif
-    default: return launch_multi<4, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+    case 1: return launch_multi<1, 4, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+    case 2: return launch_multi<2, 4, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+    case 3: return launch_multi<3, 4, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+    default: return launch_multi<4, 4, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
   }
 }
 

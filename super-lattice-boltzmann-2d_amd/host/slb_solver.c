@@ -133,7 +133,11 @@ void slb_solver_destroy(slb_solver *s)
 static void check_sweep(int rc, int line)
 {
   if (rc > 0) HandleError(rc, __FILE__, line);
-  if (rc < 0) exit(EXIT_FAILURE);
+  if (rc < 0) {
+    fprintf(stderr, "ERROR: a launch was refused (arguments or tuning variant; see the message above), %s line %d\n",
+            __FILE__, line);
+    exit(EXIT_FAILURE);
+  }
 }
 
 /* centre and stencil are both the t=0 lattice; the result is the first

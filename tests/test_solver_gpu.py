@@ -251,14 +251,16 @@ def test_double_step_bit_exact(slb, oracle, N, M, B, omega, pairs, n_chunk):
         orc.close()
 
 
-@pytest.mark.parametrize("S", [1, 2, 3, 4])
+@pytest.mark.parametrize("S,variant", [(1, 0), (2, 0), (3, 0), (4, 0), (2, 34), (3, 32), (3, 33), (4, 32)])
 @pytest.mark.parametrize("N,M,B,omega,n_chunk", [
     (1, 5, 0.5, 3.0, 0), (2, 61, 0.05, 100.0, 0), (5, 61, 0.05, 100.0, 2), (7, 300, 0.4, 10.0, 3),
     (32, 4096, 1.0, 1.0, 0), (33, 1000, 0.5, 30.0, 5), (16, 239, 0.3, 10.0, 0), (16, 240, 0.3, 10.0, 8),
-    (16, 241, 0.3, 10.0, 1), (64, 20001, 0.2, 10.0, 16),
+    (16, 241, 0.3, 10.0, 1), (64, 20001, 0.2, 10.0, 16), (16, 115, 0.3, 10.0, 0), (16, 116, 0.3, 10.0, 0),
+    (16, 117, 0.3, 10.0, 0),
 ])
-def test_multi_step_bit_exact(slb, oracle, S, N, M, B, omega, n_chunk):
-    """S loop iterations per launch (general kernel): live state equals the oracle's."""
+def test_multi_step_bit_exact(slb, oracle, S, variant, N, M, B, omega, n_chunk):
+    """S loop iterations per launch (general kernel, four columns per lane or -- variants
+    32..34 -- two): live state equals the oracle's."""
     p = oracle.make_params(N=N, M=M, B=B, omega=omega)
     slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
                   B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
@@ -267,13 +269,17 @@ def test_multi_step_bit_exact(slb, oracle, S, N, M, B, omega, n_chunk):
     L = slb.lib()
     try:
         sol.tiptoe()
-        L.slb_set_tuning(0, n_chunk, 0)
+        L.slb_set_tuning(variant, n_chunk, 0)
         for _ in range(3):
             sol.multi_step(S)
         orc.step(3 * S)
         _compare_live_state(sol, orc, M)
         assert sol.s.t == orc.st.t
-        sol.step(); sol.multi_step(S); sol.step_fused(); sol.multi_step(S)
+        for single in (sol.step, sol.step_fused):
+            L.slb_set_tuning(0, n_chunk, 0)          # the variant numbers belong to the multi-step kernel
+            single()
+            L.slb_set_tuning(variant, n_chunk, 0)
+            sol.multi_step(S)
         orc.step(2 + 2 * S)
         _compare_live_state(sol, orc, M)
     finally:
