@@ -391,3 +391,42 @@ def test_program_config2_matches_what_was_observed_on_the_reference(solver_bin, 
                        capture_output=True, text=True, timeout=600)
     assert g.returncode == 0, g.stdout + g.stderr
     _check_config2_observations((tmp_path / "out.txt").read_text())
+
+
+def test_unusual_parameters_all_forms(slb, oracle):
+    """Nothing in the kernels is tied to the usual +-4 range, mu = 5 or dt = 0.001: an
+    asymmetric phi_y range, other field strengths and a different time step give the
+    oracle's bits in every step form, and so do av() and the frame values."""
+    import ctypes as C
+    import torch
+    kw = dict(N=12, M=777, E_dc=2.5, E_omega=0.7, omega=13.0, mu=2.3, alpha=0.8, B=1.7,
+              PhiYmin=-3.0, PhiYmax=5.0, dt=0.0005)
+    p = oracle.make_params(t_start=0.2, **kw)
+    slb.configure(**kw)
+    orc = oracle.OracleState(p)
+    sol = slb.Solver()
+    L = slb.lib()
+    try:
+        sol.tiptoe()
+        for _ in range(3):
+            sol.step()
+        orc.step(3)
+        _compare_state(sol, orc, kw["M"])
+        sol.step_fused(); sol.double_step(); sol.multi_step(3); sol.step_fused()
+        orc.step(7)
+        _compare_live_state(sol, orc, kw["M"])
+        cur = orc.st.current
+        av_cpu = np.zeros(6, np.float32)
+        av_dev = torch.zeros(6, dtype=torch.float32, device="cuda")
+        L.slb_set_av_mode(slb.SLB_AV_EXACT)
+        for t in (0.3, 0.3005):
+            oracle.lib().orc_av(C.byref(p), orc.array("a", cur), orc.array("b", cur), av_cpu, np.float32(t))
+            L.av(0, sol.s.a[sol.s.current], sol.s.b[sol.s.current], av_dev.data_ptr(), np.float32(t))
+        torch.cuda.synchronize()
+        assert np.array_equal(av_dev.cpu().numpy().view(np.uint32), av_cpu.view(np.uint32))
+        phi = oracle.frame_phi_x()[::60]
+        exp = oracle.frame_values(p, orc.array("a", cur), orc.array("b", cur), phi)
+        assert np.array_equal(sol.frame_values(phi).view(np.uint32), exp.view(np.uint32))
+    finally:
+        sol.close()
+        orc.close()
