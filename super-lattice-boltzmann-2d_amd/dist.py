@@ -37,6 +37,7 @@ so the forms can be mixed freely.
 All arithmetic stays in the engine (the HIP kernels); this file only orders
 launches and moves 2*ncols*(N+1) floats per side.
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -293,20 +294,16 @@ class SlabRun:
         self._double_halo(self.recv2, pack=False)
         e.double_step_finish()                       # the spares become the current lattices
 
+    @contextlib.contextmanager
     def _on_side(self):
-        """Context: launches of the engine and of torch.distributed go to the side stream."""
-        run = self
-
-        class _Ctx:
-            def __enter__(self):
-                self.ctx = torch.cuda.stream(run.side)
-                self.ctx.__enter__()
-                run.eng.slb.lib().slb_set_stream(run.side.cuda_stream)
-
-            def __exit__(self, *exc):
-                run.eng.slb.lib().slb_set_stream(run.main.cuda_stream)
-                return self.ctx.__exit__(*exc)
-        return _Ctx()
+        """Launches of the engine and of torch.distributed go to the side stream."""
+        set_stream = self.eng.slb.lib().slb_set_stream
+        with torch.cuda.stream(self.side):
+            set_stream(self.side.cuda_stream)
+            try:
+                yield
+            finally:
+                set_stream(self.main.cuda_stream)
 
     def _double_step_two_streams(self, kw):
         e = self.eng
