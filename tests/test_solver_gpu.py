@@ -66,6 +66,16 @@ def test_program_display4_identical(solver_bin, oracle, tmp_path):
     assert "# t_max = " in g.stdout and "# norm=" in g.stdout
 
 
+@pytest.mark.parametrize("env", [None, {"SLB_FORM": "fused"}, {"SLB_AV": "chain"}])
+def test_program_display4_wide_lattice_parallel_exact_sums(solver_bin, oracle, tmp_path, env):
+    """display=4 on a lattice wide enough for the parallel form of the exact sums, fed from the
+    rows the double-step kernel hands out and summed on the side streams: the record still
+    equals the oracle's to the last digit."""
+    args = ["display=4", "omega=100", "B=0.1", "n-harmonics=8", "g-grid=70001", "t-max=0.012"] + COMMON
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args, env=env)
+    assert (gdir / "out.txt").read_text() == (odir / "out.txt").read_text()
+
+
 def test_program_display77_identical(solver_bin, oracle, tmp_path):
     """display=77 trace on a shrunken config-2 shape: every record identical,
     including the flat-index sums and the in-place rescaling of the averages."""
