@@ -77,6 +77,20 @@ def test_program_display4_wide_lattice_parallel_exact_sums(solver_bin, oracle, t
     assert (gdir / "out.txt").read_text() == (odir / "out.txt").read_text()
 
 
+def test_program_display4_tree_sums_within_rounding_noise(solver_bin, oracle, tmp_path):
+    """SLB_AV=tree: same record except that the period averages carry the difference between
+    a tree sum in double and the CPU's sequential float sum."""
+    args = ["display=4", "omega=100", "B=0.1", "n-harmonics=8", "g-grid=70001", "t-max=0.012"] + COMMON
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args, env={"SLB_AV": "tree"})
+    a, b = (gdir / "out.txt").read_text().splitlines(), (odir / "out.txt").read_text().splitlines()
+    assert a[:2] == b[:2]
+    ca, cb = a[2].split(), b[2].split()
+    assert [ca[i] for i in (0, 1, 2, 3, 4, 6, 7, 8)] == [cb[i] for i in (0, 1, 2, 3, 4, 6, 7, 8)]
+    scale = max(abs(float(cb[i])) for i in (9, 10, 11))
+    for i in (5, 9, 10, 11, 12):
+        assert abs(float(ca[i]) - float(cb[i])) <= 1e-4 * scale + 1e-9, (i, ca[i], cb[i])   # the float sum is that noisy
+
+
 def test_program_display77_identical(solver_bin, oracle, tmp_path):
     """display=77 trace on a shrunken config-2 shape: every record identical,
     including the flat-index sums and the in-place rescaling of the averages."""
