@@ -11,7 +11,8 @@
  *
  * All pointers named a*, b*, av_data, sums, buf are DEVICE pointers owned by the
  * caller.  The library keeps no pointer between calls and allocates nothing
- * per call (one small workspace is allocated on first use of the reductions).
+ * per call (one small workspace is allocated on first use of av() and
+ * slb_av_partial()).
  * Launches are asynchronous on the stream set by slb_set_stream() (default: the
  * null stream, as in the reference).
  *
@@ -234,14 +235,15 @@ int slb_av_update_exact(const float *tot3, float *av_data, float t);
  *   SLB_AV_EXACT (default) -- the terms are added in float in the reference's
  *       order, bit-identical to the reference CPU av(), but by a whole
  *       workgroup per sum: inside one binade of the running sum every addition
- *       rounds to one fixed grid, so 1024 terms at a time become an integer
+ *       rounds to one fixed grid, so 4096 terms at a time become an integer
  *       prefix sum; ties, binade changes and special values take a real float
  *       addition (see slb_seq_sum);
  *   SLB_AV_CHAIN -- the same bits from one lane per sum adding term after term
  *       (a chain of M dependent additions; kept as a cross-check);
  *   SLB_AV_TREE -- slb_av_partial + slb_av_update: wave64 shuffle tree in
  *       double; differs from the CPU's sequential float sum by that sum's own
- *       rounding noise (about 1e-6 relative at M = 2^20). */
+ *       rounding noise (about 1e-4 relative at M = 2^20 for a sum that nearly
+ *       cancels, 1e-6 for one that does not). */
 enum { SLB_AV_EXACT = 0, SLB_AV_TREE = 1, SLB_AV_CHAIN = 2 };
 void slb_set_av_mode(int mode);
 
