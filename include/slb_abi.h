@@ -229,6 +229,13 @@ int slb_av_sums_exact(const slb_slab *slab, const float *a, const float *b, floa
 /* the same for n <= 4 lattices in one launch (a[k], b[k] -> tot3[k]) */
 int slb_av_sums_exact_n(const slb_slab *slab, int n, const float *const a[], const float *const b[],
                         float *const tot3[]);
+/* the same with the running sums starting from init3[k][0..2] instead of zero (init3 or
+ * init3[k] NULL: zero; init3[k] == tot3[k] is allowed): the sums of a lattice cut into
+ * column ranges are the chain range 1 -> range 2 -> ..., each call starting from the
+ * totals of the one before -- how phi_y slabs reproduce the reference's single running
+ * sum over all columns (reference: src/boltzmann_c_solver.c:413-437) bit for bit */
+int slb_av_sums_exact_from_n(const slb_slab *slab, int n, const float *const a[], const float *const b[],
+                             const float *const init3[], float *const tot3[]);
 int slb_av_update_exact(const float *tot3, float *av_data, float t);
 
 /* How av() forms its three sums:

@@ -24,7 +24,7 @@ _INT_GLOBALS = ("host_M", "host_N", "MSIZE", "MP1", "NSIZE", "host_TMSIZE", "PAD
 # every symbol include/slb_abi.h declares
 ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "HandleError",
                  "slb_sweep", "slb_step_fused", "slb_step_fused2", "slb_step_fused2_rows", "slb_step_multi",
-                 "slb_av_sums_exact", "slb_av_sums_exact_n", "slb_av_update_exact", "slb_halo_pack", "slb_halo_unpack", "slb_halo_pack_segs", "slb_halo_unpack_segs", "slb_av_partial",
+                 "slb_av_sums_exact", "slb_av_sums_exact_n", "slb_av_sums_exact_from_n", "slb_av_update_exact", "slb_halo_pack", "slb_halo_unpack", "slb_halo_pack_segs", "slb_halo_unpack_segs", "slb_av_partial",
                  "slb_frame_values", "slb_seq_sum", "slb_seq_sum_stats",
                  "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream",
                  "slb_set_tuning", "slb_version")
@@ -126,6 +126,10 @@ def lib():
         L.slb_solver_double_step_rows.restype = None
         L.slb_av_sums_exact.argtypes, L.slb_av_sums_exact.restype = [C.POINTER(Slab), fp, fp, fp], i
         L.slb_av_update_exact.argtypes, L.slb_av_update_exact.restype = [fp, fp, f], i
+        pp = C.POINTER(C.c_void_p)
+        L.slb_av_sums_exact_from_n.argtypes = [C.POINTER(Slab), i, pp, pp, pp, pp]
+        L.slb_av_sums_exact_from_n.restype = i
+        L.slb_solver_copy_av_rows.argtypes, L.slb_solver_copy_av_rows.restype = [C.POINTER(SolverStruct), fp], i
         L.slb_solver_double_step_range.argtypes = [C.POINTER(SolverStruct), i, i, C.POINTER(C.c_float * 8)]
         L.slb_solver_double_step_range.restype = None
         L.slb_solver_double_step_range_rows.argtypes = [C.POINTER(SolverStruct), i, i, C.POINTER(C.c_float * 8), fp, fp]
@@ -309,6 +313,12 @@ class Solver:
         """double_step() that also writes a rows 0, 1 and b row 1 of both new main lattices
         into two [3][pitch] device buffers."""
         lib().slb_solver_double_step_rows(self._p, rows_first_ptr, rows_second_ptr)
+
+    def copy_av_rows(self, rows_ptr):
+        """a rows 0, 1 and b row 1 of the current main lattice -> a [3][pitch] device buffer."""
+        rc = lib().slb_solver_copy_av_rows(self._p, rows_ptr)
+        if rc:
+            raise RuntimeError(f"slb_solver_copy_av_rows -> {rc}")
 
     def av_partial(self, sums_ptr):
         rc = lib().slb_solver_av_partial(self._p, sums_ptr)

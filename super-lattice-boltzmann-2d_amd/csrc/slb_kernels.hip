@@ -1111,6 +1111,7 @@ struct AvSets {
   AvArgs geom;                       // a, b unused
   const float *a[kAvMaxSets], *b[kAvMaxSets];
   float *tot[kAvMaxSets];
+  const float *init[kAvMaxSets];     // where each lattice's three running sums start; null: at zero
 };
 __device__ __forceinline__ AvArgs av_set_args(const AvSets &s, int set)
 {
@@ -1125,6 +1126,14 @@ __device__ __forceinline__ float *av_set_tot(const AvSets &s, int set)
 #pragma unroll
   for (int k = 1; k < kAvMaxSets; k++) if (k == set) t = s.tot[k];
   return t;
+}
+
+__device__ __forceinline__ float av_set_init(const AvSets &s, int set, int q)
+{
+  const float *t = s.init[0];
+#pragma unroll
+  for (int k = 1; k < kAvMaxSets; k++) if (k == set) t = s.init[k];
+  return t ? t[q] : 0.0f;
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -1207,7 +1216,7 @@ __global__ void __launch_bounds__(64) av_exact_kernel(const AvSets sets)
   const AvArgs p = av_set_args(sets, set);
   float *tot = av_set_tot(sets, set);
   const int lane = threadIdx.x;
-  float acc = 0.0f;
+  float acc = av_set_init(sets, set, q);
   float term[T];
   int base = p.j_first;
 #pragma unroll
@@ -1294,7 +1303,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int v)
 }
 
 template <int W, int T, class F>
-__device__ float seq_sum_block(F term, int n, ScanShared<W, T> &sh, int *stats = nullptr)
+__device__ float seq_sum_block(F term, int n, ScanShared<W, T> &sh, int *stats = nullptr, float start = 0.0f)
 {
   constexpr int kScanChunk = 64 * W * T;
   // |rint(h)| < 2^18 for every term of a chunk keeps all prefix sums inside an int
@@ -1302,7 +1311,7 @@ __device__ float seq_sum_block(F term, int n, ScanShared<W, T> &sh, int *stats =
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int e0 = tid * T;                                  // my first term's index in the chunk
   int n_passes = 0, n_bursts = 0, burst = kScanBurst;
-  float acc = 0.0f;
+  float acc = start;
   float x[T], x_next[T];
 #pragma unroll
   for (int t = 0; t < T; t++) x_next[t] = e0 + t < n ? term(e0 + t) : 0.0f;
@@ -1445,7 +1454,8 @@ __global__ void __launch_bounds__(64 * kAvScanWaves) av_exact_scan_kernel(const 
   const int set = blockIdx.x / 3, q = blockIdx.x % 3;
   const AvArgs p = av_set_args(sets, set);
   const float acc = seq_sum_block<kAvScanWaves, kAvScanPerLane>(
-      [&](int i) { return av_term(p, q, p.j_first + i); }, p.j_last - p.j_first + 1, sh);
+      [&](int i) { return av_term(p, q, p.j_first + i); }, p.j_last - p.j_first + 1, sh, nullptr,
+      av_set_init(sets, set, q));
   if (threadIdx.x == 0) av_set_tot(sets, set)[q] = acc;
 }
 
@@ -2030,17 +2040,18 @@ int slb_av_update(const double *sums, float *av_data, float t)
   return (int)hipGetLastError();
 }
 
-int slb_av_sums_exact_n(const slb_slab *slab, int n, const float *const a[], const float *const b[],
-                        float *const tot3[])
+int slb_av_sums_exact_from_n(const slb_slab *slab, int n, const float *const a[], const float *const b[],
+                             const float *const init3[], float *const tot3[])
 {
   if (!g_phys.loaded || !slab || slab->j_first < 0 || slab->j_last >= slab->pitch ||
-      n < 1 || n > kAvMaxSets || !a || !b || !tot3) return -1;
+      slab->j_last < slab->j_first || n < 1 || n > kAvMaxSets || !a || !b || !tot3) return -1;
   AvSets sets;
   sets.geom = make_av_args(slab, nullptr, nullptr);
   for (int k = 0; k < kAvMaxSets; k++) {
     const int src = k < n ? k : 0;
     if (!a[src] || !b[src] || !tot3[src]) return -1;
     sets.a[k] = a[src]; sets.b[k] = b[src]; sets.tot[k] = tot3[src];
+    sets.init[k] = init3 ? init3[src] : nullptr;
   }
   // both kernels give the CPU's bits; below a few ten thousand columns the one-lane chain is
   // done before the parallel form has paid for its passes
@@ -2049,6 +2060,12 @@ int slb_av_sums_exact_n(const slb_slab *slab, int n, const float *const a[], con
   else
     hipLaunchKernelGGL(av_exact_scan_kernel, dim3(3 * n), dim3(64 * kAvScanWaves), 0, g_stream, sets);
   return (int)hipGetLastError();
+}
+
+int slb_av_sums_exact_n(const slb_slab *slab, int n, const float *const a[], const float *const b[],
+                        float *const tot3[])
+{
+  return slb_av_sums_exact_from_n(slab, n, a, b, nullptr, tot3);
 }
 
 int slb_av_sums_exact(const slb_slab *slab, const float *a, const float *b, float *tot3)

@@ -37,6 +37,7 @@ so the forms can be mixed freely.
 All arithmetic stays in the engine (the HIP kernels); this file only orders
 launches and moves 2*ncols*(N+1) floats per side.
 """
+import collections
 import contextlib
 import ctypes as C
 
@@ -93,6 +94,77 @@ class HipEngine:
     def double_step_finish(self):
         self.sol.double_step_finish()
 
+    # -- the pieces ExactAvChain needs ------------------------------------------
+    def new_chain_slot(self):
+        slot = _ChainSlot()
+        slot.rows = (self.new_rows(), self.new_rows())
+        # running sums of up to two iterations: where they start (from the slab before) and
+        # where they end, on the device and in pinned host memory for the messages
+        slot.init, slot.tot = (torch.zeros(6, dtype=torch.float32).pin_memory() for _ in range(2))
+        slot.init_dev, slot.tot_dev = (torch.zeros(6, dtype=torch.float32, device=self.device) for _ in range(2))
+        slot.done = None
+        return slot
+
+    def new_av_data(self):
+        return torch.zeros(6, dtype=torch.float32, device=self.device)
+
+    def copy_av_rows(self, rows):
+        self.sol.copy_av_rows(rows.data_ptr())
+
+    def mark(self):
+        """An event after everything queued so far on the current stream."""
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def chain_launch(self, slot, n, use_init, events, av_data, times):
+        """Queue, on the stream of the sums and after `events`, the exact-order sums of the
+        first n row buffers of `slot`, starting from slot.init (else zero); then either the
+        updates of av_data for `times` (last slab) or the copy of the totals to slot.tot."""
+        lib = self.slb.lib()
+        if getattr(self, "av_stream", None) is None:
+            self.av_stream = torch.cuda.Stream()
+        st = self.av_stream
+        for ev in events:
+            st.wait_event(ev)
+        vp = C.c_void_p
+        pitch = self.sol.s.pitch
+        a = (vp * n)(*[slot.rows[k].data_ptr() for k in range(n)])
+        b = (vp * n)(*[slot.rows[k].data_ptr() + 4 * pitch for k in range(n)])        # b + pitch floats = row 2
+        ini = (vp * n)(*[slot.init_dev.data_ptr() + 12 * k for k in range(n)])
+        tot = (vp * n)(*[slot.tot_dev.data_ptr() + 12 * k for k in range(n)])
+        before = lib.slb_get_stream()
+        with torch.cuda.stream(st):
+            lib.slb_set_stream(st.cuda_stream)
+            try:
+                if use_init:
+                    slot.init_dev.copy_(slot.init, non_blocking=True)
+                rc = lib.slb_av_sums_exact_from_n(C.byref(self.sol.s.av_slab), n, a, b, ini if use_init else None, tot)
+                if rc:
+                    raise RuntimeError(f"slb_av_sums_exact_from_n -> {rc}")
+                if times is not None:
+                    for k, t in enumerate(times):
+                        rc = lib.slb_av_update_exact(slot.tot_dev.data_ptr() + 12 * k, av_data.data_ptr(), t)
+                        if rc:
+                            raise RuntimeError(f"slb_av_update_exact -> {rc}")
+                else:
+                    slot.tot.copy_(slot.tot_dev, non_blocking=True)
+            finally:
+                lib.slb_set_stream(before)
+            slot.done = torch.cuda.Event()
+            slot.done.record(st)
+
+    def chain_done(self, slot, block):
+        if block:
+            slot.done.synchronize()
+            return True
+        return slot.done.query()
+
+    def av_data_host(self, av_data):
+        if getattr(self, "av_stream", None) is not None:
+            self.av_stream.synchronize()
+        return av_data.cpu()
+
     def av_partial(self):
         sums = torch.zeros(4, dtype=torch.float64, device=self.device)
         self.sol.av_partial(sums.data_ptr())
@@ -125,6 +197,10 @@ class HipEngine:
 
     def close(self):
         self.sol.close()
+
+
+class _ChainSlot:
+    pass
 
 
 class SlabRun:
@@ -376,8 +452,129 @@ class SlabRun:
                 dist.all_reduce(sums, group=self.group)
         self.eng.av_update(sums, av_data, t)
 
+    def rows_written(self):
+        """Events after which the row buffers of the last double_step(rows=...) are complete."""
+        if self.side is not None and self.side_busy:
+            return [self.ev_main, self.ev_side]      # interior launch; edge launches and halo chain
+        return [self.eng.mark()]
+
     def close(self):
         self.join()
         if self.side is not None:
             torch.cuda.synchronize()
         self.eng.close()
+
+
+class ExactAvChain:
+    """av() over phi_y slabs with the bits of the reference's av(): its three sums are float
+    running sums over ALL columns in order (reference: src/boltzmann_c_solver.c:413-437), so
+    slab r has to start from the totals slab r-1 ended with.  The totals of one iteration
+    (3 floats; 6 for a double step) travel down the chain of ranks as host messages; the last
+    slab applies the running-average updates in step order, and finish() hands av_data to
+    every rank.  The sums of different iterations do not depend on each other, so nothing
+    here blocks the time loop: an iteration's rows wait in one of `slots` buffers until the
+    totals from the left have arrived, and the loop only waits when it needs a buffer back.
+
+        slot = chain.acquire()
+        run.double_step(rows=slot.rows)
+        chain.submit(slot, [t, t + dt])          # or [t] / only_second=True, see submit()
+        ...
+        av6 = chain.finish()
+    """
+
+    def __init__(self, run, slots=16, lockstep=None):
+        self.run, self.eng = run, run.eng
+        self.rank, self.world = run.rank, run.world
+        # With halos staged through host memory (gloo rehearsals) an exchange blocks the host
+        # until the neighbours have posted theirs; a rank waiting here for totals from a rank
+        # that waits there for its halo would never be served.  There every submit() sees its
+        # iteration through (ranks then move in step); over RCCL, where exchanges only block
+        # streams, iterations are left in flight.
+        self.lockstep = run.cpu_staging if lockstep is None else lockstep
+        self.is_first, self.is_last = self.rank == 0, self.rank == self.world - 1
+        self.group = None
+        if self.world > 1:
+            # few-byte host messages on a gloo group of their own, so that they are never
+            # matched with halo messages between the same two ranks
+            self.group = dist.new_group(backend="gloo")
+        self.free = [self.eng.new_chain_slot() for _ in range(slots)]
+        self.queue = collections.deque()
+        self.av_data = self.eng.new_av_data()
+        self.seq = 1
+
+    def acquire(self):
+        while not self.free:
+            self._advance(block=True)
+        return self.free.pop()
+
+    def submit(self, slot, times, only_second=False):
+        """The double step (or copy) that fills slot.rows has been queued.  times: loop times
+        of the iterations to average, in order: both iterations of the double step, or one --
+        the first row buffer, or with only_second the second (averaging starts between the
+        two iterations)."""
+        n = len(times)
+        if only_second:
+            slot.rows = (slot.rows[1], slot.rows[0])
+        item = _ChainSlot()
+        item.slot, item.n, item.times, item.stage = slot, n, [float(t) for t in times], 0
+        item.events = self.run.rows_written()
+        item.tag = self.seq
+        self.seq += 1
+        item.recv = item.send = None
+        if not self.is_first:
+            item.recv = dist.irecv(slot.init[:3 * n], src=self.rank - 1, group=self.group, tag=item.tag)
+        self.queue.append(item)
+        if self.lockstep:
+            while self.queue:
+                self._advance(block=True)
+        else:
+            self._advance(block=False)
+
+    def submit_current(self, t):
+        """av() of the current main lattice (after a single step)."""
+        slot = self.acquire()
+        self.eng.copy_av_rows(slot.rows[0])
+        self.submit(slot, [t])
+
+    def _advance(self, block):
+        """Move every queued iteration as far as it can go without waiting; with block, wait
+        for the oldest one to finish."""
+        launched_all_before = True
+        for k, it in enumerate(self.queue):
+            wait = block and k == 0
+            if it.stage == 0:                              # totals from the left slab not here yet
+                if not launched_all_before:
+                    break
+                if it.recv is not None:
+                    if wait:
+                        it.recv.wait()
+                    elif not it.recv.is_completed():
+                        launched_all_before = False
+                        continue
+                self.eng.chain_launch(it.slot, it.n, it.recv is not None, it.events,
+                                      self.av_data, it.times if self.is_last else None)
+                it.stage = 1
+            if it.stage == 1:                              # sums running
+                if not self.eng.chain_done(it.slot, wait):
+                    continue
+                if self.is_last:
+                    it.stage = 3
+                else:
+                    it.send = dist.isend(it.slot.tot[:3 * it.n], dst=self.rank + 1, group=self.group, tag=it.tag)
+                    it.stage = 2
+            if it.stage == 2:                              # totals on their way to the right slab
+                if wait:
+                    it.send.wait()
+                if wait or it.send.is_completed():
+                    it.stage = 3
+        while self.queue and self.queue[0].stage == 3:
+            self.free.append(self.queue.popleft().slot)
+
+    def finish(self):
+        """Wait for everything submitted; returns av_data (6 floats, numpy) on every rank."""
+        while self.queue:
+            self._advance(block=True)
+        host = self.eng.av_data_host(self.av_data)
+        if self.world > 1:
+            dist.broadcast(host, src=self.world - 1, group=self.group)
+        return host.numpy().copy()

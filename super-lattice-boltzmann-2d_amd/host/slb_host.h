@@ -137,6 +137,9 @@ int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const 
 /* av() over slabs: each slab's partial sums (3 doubles, device) of its own columns of
  * the current main lattice; add them across slabs, then slb_av_update(sums, av_data, t) */
 int slb_solver_av_partial(slb_solver *s, double *sums);
+/* the three rows av() reads of the current main lattice -> a [3][pitch] device buffer
+ * (a row 0, a row 1, b row 1), on the launch stream */
+int slb_solver_copy_av_rows(slb_solver *s, float *rows);
 
 /* halo traffic of a double step in one launch per direction: per neighbour a buffer of
  * 2*7*(N+1) floats (3 main-lattice columns, then 4 half-step columns, taken from / put

@@ -535,6 +535,20 @@ int slb_solver_av_partial(slb_solver *s, double *sums)
   return slb_av_partial(&s->av_slab, s->a[s->current], s->b[s->current], sums);
 }
 
+/* the rows av() reads of the CURRENT main lattice (a rows 0 and 1, b row 1) copied into a
+ * [3][pitch] device buffer on the launch stream: the form in which the double step hands
+ * them out, for a single step in between */
+int slb_solver_copy_av_rows(slb_solver *s, float *rows)
+{
+  const size_t row_bytes = sizeof(float) * (size_t)s->pitch;
+  hipStream_t st = (hipStream_t)slb_get_stream();
+  hipError_t e = hipMemcpyAsync(rows, s->a[s->current], 2 * row_bytes, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(rows + 2 * (size_t)s->pitch, s->b[s->current] + s->pitch, row_bytes,
+                       hipMemcpyDeviceToDevice, st);
+  return (int)e;
+}
+
 /* Frame values (display=3/7/8/9) of this slab's main-lattice columns (main_slab.j_first..
  * j_last; 1..M+1 for a single slab) for nphi values of phi_x: out (host) receives
  * nphi x ncols floats, row p = phi_x[p].  source 0: the current lattice a, b;

@@ -8,8 +8,10 @@ Same name=value parameters (read by the same C parser) and the same display=4 re
 the single-GPU program (reference: src/boltzmann_solver.c:74-401).  The lattices are
 bit-identical to a single-GPU run; the instantaneous sums and the norm are formed on
 rank 0 from the three rows they need, in the reference's order, so those columns are
-bit-identical too.  The period averages use av() over slabs (per-slab sums in double,
-all-reduced), which differs from the CPU's sequential float sums by their rounding noise.
+bit-identical too.  The period averages come from av() over slabs with the running sums
+handed from slab to slab (dist.ExactAvChain), so they too have the single-GPU program's
+bits; SLB_AV=tree selects per-slab sums in double, all-reduced, which differ from the CPU's
+sequential float sums by their rounding noise.
 SLB_DIST_BACKEND=gloo stages the halo messages through host memory (rehearsals with
 several ranks on one GPU).
 """
@@ -66,11 +68,13 @@ def main(argv):
     if world > 1:
         torch.cuda.set_stream(torch.cuda.Stream())    # not the legacy null stream (implicit synchronisation)
     L.slb_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
-    L.slb_set_av_mode(slb.SLB_AV_TREE)
+    tree = os.environ.get("SLB_AV") == "tree"
+    L.slb_set_av_mode(slb.SLB_AV_TREE if tree else slb.SLB_AV_EXACT)
     run = drv.SlabRun(slb, rank, world)
     sol = run.eng.sol
     run.tiptoe()
     av_data = torch.zeros(6, dtype=torch.float32, device="cuda")
+    chain = None if tree else drv.ExactAvChain(run)
 
     def averaged(t):
         return E_omega > 0 and t >= t_start
@@ -84,16 +88,25 @@ def main(argv):
         if t2 < t_max and averaged(t) == averaged(t2):
             if averaged(t):
                 # two iterations per launch; the launch also hands out the rows av() reads of both
-                run.double_step(rows=rows)
-                run.av_rows(rows[0], av_data, float(t))
-                run.av_rows(rows[1], av_data, float(t2))
+                if chain is not None:
+                    slot = chain.acquire()
+                    run.double_step(rows=slot.rows)
+                    chain.submit(slot, [t, t2])
+                else:
+                    run.double_step(rows=rows)
+                    run.av_rows(rows[0], av_data, float(t))
+                    run.av_rows(rows[1], av_data, float(t2))
             else:
                 run.double_step()
             continue
         run.step_fused()
         if averaged(t):
-            run.av(av_data, float(t))
+            if chain is not None:
+                chain.submit_current(t)
+            else:
+                run.av(av_data, float(t))
     t = np.float32(sol.s.t)
+    av6 = chain.finish() if chain is not None else av_data.cpu().numpy().copy()
 
     # the three rows the record's sums read, put together on rank 0
     s = sol.s
@@ -118,7 +131,6 @@ def main(argv):
         L.slb_write_display4.argtypes = [C.c_float, fp, fp, C.c_int, fp, C.c_float]
         L.slb_write_display4.restype = None
         norm = L.slb_host_norm(a_rows.ctypes.data, M, g("host_dPhi"), g("host_alpha"))
-        av6 = av_data.cpu().numpy().copy()
         L.slb_write_display4(norm, a_rows.ctypes.data, b_row.ctypes.data, M + 3, av6.ctypes.data, float(T))
         L.slb_close_output.argtypes, L.slb_close_output.restype = [], None
         L.slb_close_output()

@@ -121,7 +121,7 @@ class OracleEngine:
         self.t = t
         return c + c2
 
-    def double_step_range(self, j_first, j_last, c):
+    def double_step_range(self, j_first, j_last, c, rows=None):
         if getattr(self, "sp_of", None) != (self.cur, self.cur_hs):
             self.sp_a, self.sp_b = self.a[self.cur].copy(), self.b[self.cur].copy()
             self.sp_ah, self.sp_bh = self.a[self.cur_hs].copy(), self.b[self.cur_hs].copy()
@@ -145,6 +145,14 @@ class OracleEngine:
         self._sweep(jf[1], jl[1], self.a[self.cur_hs], self.b[self.cur_hs], o1a, o1b, o2a, o2b, c[2], c[3])
         self._sweep(jf[2], jl[2], o1a, o1b, o2a, o2b, self.sp_a, self.sp_b, c[4], c[5])
         self._sweep(jf[3], jl[3], o2a, o2b, self.sp_a, self.sp_b, self.sp_ah, self.sp_bh, c[6], c[7])
+        if rows is not None:
+            # the rows av() reads of both new main lattices, for the columns this launch wrote
+            for buf, (ra, rb), (lo_c, hi_c) in ((rows[0], (o1a, o1b), (jf[0], jl[0])),
+                                               (rows[1], (self.sp_a, self.sp_b), (jf[2], jl[2]))):
+                v = buf.numpy()
+                v[0, lo_c:hi_c + 1] = ra[0, lo_c:hi_c + 1]
+                v[1, lo_c:hi_c + 1] = ra[1, lo_c:hi_c + 1]
+                v[2, lo_c:hi_c + 1] = rb[1, lo_c:hi_c + 1]
 
     def double_step_finish(self):
         self.a[self.cur], self.sp_a = self.sp_a, self.a[self.cur]
@@ -153,6 +161,60 @@ class OracleEngine:
         self.b[self.cur_hs], self.sp_bh = self.sp_bh, self.b[self.cur_hs]
         self.advance()
         self.advance()
+
+    # -- what ExactAvChain needs, with the CPU solver's arithmetic ----------------
+    # (reference: src/boltzmann_c_solver.c:413-437, the sums cut at the slab's columns)
+    def new_rows(self):
+        return self.torch.zeros((3, self.pitch), dtype=self.torch.float32)
+
+    def new_chain_slot(self):
+        class Slot:
+            pass
+        slot = Slot()
+        slot.rows = (self.new_rows(), self.new_rows())
+        slot.init = self.torch.zeros(6, dtype=self.torch.float32)
+        slot.tot = self.torch.zeros(6, dtype=self.torch.float32)
+        return slot
+
+    def new_av_data(self):
+        return self.torch.zeros(6, dtype=self.torch.float32)
+
+    def copy_av_rows(self, rows):
+        v = rows.numpy()
+        v[0], v[1], v[2] = self.a[self.cur][0], self.a[self.cur][1], self.b[self.cur][1]
+
+    def mark(self):
+        return None
+
+    def chain_launch(self, slot, n, use_init, events, av_data, times):
+        f = np.float32
+        p = self.p
+        dPhi, ymin = f(p.dPhi), f(p.PhiYmin)
+        for k in range(n):
+            v = slot.rows[k].numpy()
+            acc = [f(x) for x in slot.init[3 * k:3 * k + 3].numpy()] if use_init else [f(0), f(0), f(0)]
+            for j in range(self.G, self.G + self.W):
+                phi = f(ymin + f(dPhi * f(self.m_offset + j - 1)))
+                acc[0] = f(acc[0] + f(v[2, j] * dPhi))
+                acc[1] = f(acc[1] + f(f(v[0, j] * phi) * dPhi))
+                acc[2] = f(acc[2] + f(v[1, j] * dPhi))
+            slot.tot[3 * k:3 * k + 3] = self.torch.tensor([float(x) for x in acc], dtype=self.torch.float32)
+            if times is not None:
+                av = av_data.numpy()
+                t = f(times[k])
+                count = int(f(av[0] + f(1)))
+                for q in range(3):
+                    av[1 + q] = f(av[1 + q] + f(f(acc[q] - av[1 + q]) / f(count)))
+                wt = np.float64(f(f(p.omega) * t))
+                av[4] = f(np.float64(av[4]) + np.cos(wt) * np.float64(acc[0]) * np.float64(f(p.dt)))
+                av[5] = f(np.float64(av[5]) + np.sin(wt) * np.float64(acc[0]) * np.float64(f(p.dt)))
+                av[0] = f(av[0] + f(1))
+
+    def chain_done(self, slot, block):
+        return True
+
+    def av_data_host(self, av_data):
+        return av_data
 
     def swap(self):
         self.cur, self.nxt = self.nxt, self.cur
@@ -171,6 +233,49 @@ class OracleEngine:
         lo = G - 1 if self.rank == 0 else G                     # rank 0 adds boundary column 0
         hi = G + self.W + 2 if self.rank == self.world - 1 else G + self.W   # last adds M+1, M+2
         return arr[:, lo:hi].copy()
+
+
+# steps of an averaging period: double steps averaged after both iterations, after the
+# second only (averaging starts in between), after the first only; single steps
+AV_PLAN = ("second", "both", "single", "both", "first", "single", "both")
+
+
+def run_av_plan(run, chain, now, dt):
+    """Drive AV_PLAN through a SlabRun + ExactAvChain; now() = the engine's loop time."""
+    for kind in AV_PLAN:
+        t = np.float32(now())
+        t2 = np.float32(t + dt)
+        if kind == "single":
+            run.step_fused()
+            chain.submit_current(t)
+            continue
+        slot = chain.acquire()
+        run.double_step(rows=slot.rows)
+        if kind == "both":
+            chain.submit(slot, [t, t2])
+        elif kind == "first":
+            chain.submit(slot, [t])
+        else:
+            chain.submit(slot, [t2], only_second=True)
+    return chain.finish()
+
+
+def reference_av_plan(ob, p):
+    """av_data after AV_PLAN on the single-domain oracle."""
+    ref = ob.OracleState(p, threads=1)
+    av_ref = np.zeros(6, dtype=np.float32)
+    todo = {"single": [True], "both": [True, True], "first": [True, False], "second": [False, True]}
+    for kind in AV_PLAN:
+        for averaged in todo[kind]:
+            t = np.float32(ref.st.t)            # av() gets the loop time the step started from
+            ref.step(1)
+            if averaged:
+                # the lattice the step wrote is the current one after the swap
+                a_cur, b_cur = ref.array("a", ref.st.current), ref.array("b", ref.st.current)
+                ob.lib().orc_av(C.byref(p), np.ascontiguousarray(a_cur), np.ascontiguousarray(b_cur), av_ref, t)
+    ref.close()
+    assert av_ref[0] == sum(sum(todo[k]) for k in AV_PLAN)
+    return av_ref
 
 
 def free_port():

@@ -68,6 +68,36 @@ def test_slab_driver_matches_single_domain(world, mode, tmp_path):
     ref.close()
 
 
+def _av_worker(rank, world, port, outdir, lockstep):
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    slb, drv = sh.import_pkg()
+    p = ob.make_params(**PHYS)
+    eng = sh.OracleEngine(ob, p, rank, world)
+    run = drv.SlabRun(slb, rank, world, engine=eng)
+    chain = drv.ExactAvChain(run, slots=8, lockstep=lockstep)
+    run.tiptoe()
+    av = sh.run_av_plan(run, chain, lambda: eng.t, np.float32(p.dt))
+    np.save(os.path.join(outdir, f"av{rank}.npy"), av)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,lockstep", [(1, False), (2, False), (3, False), (3, True)])
+def test_exact_av_chain_over_slabs_has_the_single_domain_bits(world, lockstep, tmp_path):
+    """The running sums of av() handed from slab to slab: av_data on every rank equals the
+    oracle's av() over the whole lattice, bit for bit, whatever mix of steps fed it."""
+    if world == 1:
+        _av_worker(0, 1, 0, str(tmp_path), lockstep)
+    else:
+        mp.spawn(_av_worker, args=(world, sh.free_port(), str(tmp_path), lockstep), nprocs=world, join=True)
+    av_ref = sh.reference_av_plan(ob, ob.make_params(**PHYS))
+    for r in range(world):
+        got = np.load(tmp_path / f"av{r}.npy")
+        assert np.array_equal(got.view(np.uint32), av_ref.view(np.uint32)), (r, got, av_ref)
+
+
 def test_slab_columns_cover_the_grid():
     for M in (7, 100, 101, 4096):
         for world in (1, 2, 3, 8):

@@ -97,11 +97,75 @@ def test_slabs_on_one_gpu(world, mode, tmp_path):
     ref.close()
 
 
+def _av_worker(rank, world, port, outdir, phys):
+    import faulthandler
+    import torch
+    faulthandler.dump_traceback_later(300, exit=True)
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    slb, drv = sh.import_pkg()
+    p = ob.make_params(**phys)
+    slb.configure(N=p.N, M=p.M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    torch.cuda.set_stream(torch.cuda.Stream())
+    slb.lib().slb_set_stream(torch.cuda.current_stream().cuda_stream)
+    run = drv.SlabRun(slb, rank, world)
+    chain = drv.ExactAvChain(run, slots=4)          # fewer slots than iterations: buffers come back
+    run.tiptoe()
+    av = sh.run_av_plan(run, chain, lambda: run.eng.sol.s.t, np.float32(p.dt))
+    np.save(os.path.join(outdir, f"av{rank}.npy"), av)
+    run.close()
+    slb.lib().slb_set_stream(None)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,phys", [
+    (1, PHYS), (2, PHYS), (3, PHYS),
+    (3, dict(N=8, M=120001, B=0.8, omega=40.0, E_omega=0.3)),     # slabs wide enough for the parallel form of the sums
+])
+def test_exact_av_over_slabs_on_one_gpu(world, phys, tmp_path):
+    """av() with the running sums handed from slab to slab (HIP kernels, `world` processes on
+    one GPU): av_data on every rank has the bits of the oracle's av() over the whole lattice."""
+    if world == 1:
+        _av_worker(0, 1, 0, str(tmp_path), phys)
+    else:
+        mp.spawn(_av_worker, args=(world, sh.free_port(), str(tmp_path), phys), nprocs=world, join=True)
+    av_ref = sh.reference_av_plan(ob, ob.make_params(**phys))
+    for r in range(world):
+        got = np.load(tmp_path / f"av{r}.npy")
+        assert np.array_equal(got.view(np.uint32), av_ref.view(np.uint32)), (r, got, av_ref)
+
+
 @pytest.mark.parametrize("world", [1, 3])
 def test_slab_program_writes_the_single_gpu_record(world, tmp_path, solver_bin):
-    """slab_program.py (display=4 over slabs; here `world` processes on one GPU over gloo):
-    the instantaneous columns and the norm are the single-GPU program's to the last digit,
-    the period averages agree to the rounding noise of a float running sum."""
+    """slab_program.py (display=4 over slabs; here `world` processes on one GPU over gloo)
+    writes the single-GPU program's record, every column to the last digit: the lattices are
+    the same and the running sums of av() are handed from slab to slab."""
+    import subprocess
+    args = ["display=4", "E_dc=1", "E_omega=0.1", "omega=100", "mu=5", "alpha=1", "B=0.5", "PhiYmin=-4",
+            "PhiYmax=4", "dt=0.001", "n-harmonics=16", "g-grid=4001", "t-max=0.03", "quiet=1"]
+    one = subprocess.run([solver_bin] + args + ["o=one.txt"], cwd=tmp_path, capture_output=True, text=True,
+                         timeout=300)
+    assert one.returncode == 0, one.stdout + one.stderr
+    script = os.path.join(sh.ROOT, sh.PKG, "slab_program.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(sh.free_port()), script] + args + ["o=slabs.txt"]
+    many = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600,
+                          env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
+    assert many.returncode == 0, many.stdout + many.stderr
+    a, b = (tmp_path / "one.txt").read_text().splitlines(), (tmp_path / "slabs.txt").read_text().splitlines()
+    assert a == b and len(a) == 3
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_slab_program_with_tree_sums(world, tmp_path, solver_bin):
+    """The same with SLB_AV=tree (per-slab sums in double, all-reduced): the instantaneous
+    columns and the norm are the single-GPU program's to the last digit, the period averages
+    agree to the rounding noise of a float running sum."""
     import subprocess
     args = ["display=4", "E_dc=1", "E_omega=0.1", "omega=100", "mu=5", "alpha=1", "B=0.5", "PhiYmin=-4",
             "PhiYmax=4", "dt=0.001", "n-harmonics=16", "g-grid=4001", "t-max=0.03", "quiet=1"]
@@ -112,7 +176,7 @@ def test_slab_program_writes_the_single_gpu_record(world, tmp_path, solver_bin):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(sh.free_port()), script] + args + ["o=slabs.txt"]
     many = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600,
-                          env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
+                          env={**os.environ, "SLB_DIST_BACKEND": "gloo", "SLB_AV": "tree"})
     assert many.returncode == 0, many.stdout + many.stderr
     a, b = (tmp_path / "one.txt").read_text().splitlines(), (tmp_path / "slabs.txt").read_text().splitlines()
     assert len(a) == len(b) == 3 and a[:2] == b[:2]

@@ -87,6 +87,49 @@ def test_av_modes_agree_with_cpu(slb, oracle, M):
         L.slb_set_av_mode(slb.SLB_AV_EXACT)
 
 
+@pytest.mark.parametrize("M,cuts", [(1021, (1, 400, 401)), (40000, (13, 20000)), (150000, (40000, 100000)),
+                                    (1 << 20, (300000, 700001))])
+def test_av_sums_carried_over_column_ranges(slb, oracle, M, cuts):
+    """The exact sums of a lattice cut into column ranges, each range starting from the totals
+    of the one before (one-lane form for narrow ranges, parallel form for wide ones, two
+    lattices per launch): the totals after the last range are the CPU's sums over all columns."""
+    import torch
+    L = slb.lib()
+    N = 2
+    p = oracle.make_params(N=N, M=M, B=0.5, omega=2.0)
+    d = slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                      B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    pitch = d["PADDED_MSIZE"]
+    rng = np.random.default_rng(M + 1)
+    phi = np.linspace(-4, 4, pitch)
+    env = np.exp(-2.5 * phi ** 2)
+    lattices = []
+    for k in range(2):
+        a = (env[None, :] * (1 + 0.1 * rng.standard_normal((N + 1, pitch)))).astype(np.float32)
+        b = (env[None, :] * 0.3 * rng.standard_normal((N + 1, pitch))).astype(np.float32)
+        lattices.append((a, b))
+    dev = [(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()) for a, b in lattices]
+    L.slb_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    vp = C.c_void_p
+    tot = torch.full((2, 3), 7.0, dtype=torch.float32, device="cuda")
+    a_arr = (vp * 2)(dev[0][0].data_ptr(), dev[1][0].data_ptr())
+    b_arr = (vp * 2)(dev[0][1].data_ptr(), dev[1][1].data_ptr())
+    t_arr = (vp * 2)(tot.data_ptr(), tot.data_ptr() + 12)
+    edges = [1] + [c + 1 for c in cuts] + [M + 1]           # columns 1..M
+    for r, (lo, hi) in enumerate(zip(edges[:-1], edges[1:])):
+        slab = slb.Slab(pitch, 0, lo, hi - 1)
+        rc = L.slb_av_sums_exact_from_n(C.byref(slab), 2, a_arr, b_arr, None if r == 0 else t_arr, t_arr)
+        assert rc == 0
+    torch.cuda.synchronize()
+    got = tot.cpu().numpy()
+    f = np.float32
+    for k, (a, b) in enumerate(lattices):
+        ph = (f(p.PhiYmin) + f(p.dPhi) * np.arange(0, M, dtype=np.float32)).astype(np.float32)
+        terms = (b[1, 1:M + 1] * f(p.dPhi), (a[0, 1:M + 1] * ph) * f(p.dPhi), a[1, 1:M + 1] * f(p.dPhi))
+        exp = np.array([oracle.seq_sum(np.ascontiguousarray(x, dtype=np.float32)) for x in terms], np.float32)
+        assert np.array_equal(got[k].view(np.uint32), exp.view(np.uint32)), (k, got[k], exp)
+
+
 def test_seq_sum_fuzz(slb, oracle):
     """Many random term streams of assorted shapes: magnitudes spread over a few to sixty
     binades, runs of equal terms, sign patterns, sparse large terms, cancellation."""
