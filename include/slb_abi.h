@@ -226,7 +226,7 @@ int slb_av_update(const double *sums, float *av_data, float t);
  * floats; nothing shared between calls, so several may run on different streams
  * at once), and the update of av_data[0..5] at loop time t from such sums. */
 int slb_av_sums_exact(const slb_slab *slab, const float *a, const float *b, float *tot3);
-/* the same for n <= 4 lattices in one launch (a[k], b[k] -> tot3[k]) */
+/* the same for n <= 8 lattices in one launch (a[k], b[k] -> tot3[k]) */
 int slb_av_sums_exact_n(const slb_slab *slab, int n, const float *const a[], const float *const b[],
                         float *const tot3[]);
 /* the same with the running sums starting from init3[k][0..2] instead of zero (init3 or

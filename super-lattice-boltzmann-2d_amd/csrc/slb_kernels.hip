@@ -1105,8 +1105,8 @@ __device__ __forceinline__ float av_term(const AvArgs &p, int q, int j)
   return p.a[j] * phi * p.dPhi;
 }
 
-// up to four lattices' sums in one launch: workgroup 3*set + q forms sum q of lattice `set`
-constexpr int kAvMaxSets = 4;
+// up to eight lattices' sums in one launch: workgroup 3*set + q forms sum q of lattice `set`
+constexpr int kAvMaxSets = 8;
 struct AvSets {
   AvArgs geom;                       // a, b unused
   const float *a[kAvMaxSets], *b[kAvMaxSets];

@@ -117,42 +117,53 @@ class HipEngine:
         ev.record()
         return ev
 
-    def chain_launch(self, slot, n, use_init, events, av_data, times):
-        """Queue, on the stream of the sums and after `events`, the exact-order sums of the
-        first n row buffers of `slot`, starting from slot.init (else zero); then either the
-        updates of av_data for `times` (last slab) or the copy of the totals to slot.tot."""
+    def chain_launch(self, items, av_data, update):
+        """Queue, on the stream of the sums, ONE launch with the exact-order sums of the row
+        buffers of `items` (each: .slot, .n row buffers, .use_init, .events to wait for,
+        .times), every set starting from its slot.init (else zero); then either the updates
+        of av_data in item order (update: last slab) or the copies of the totals to slot.tot."""
         lib = self.slb.lib()
         if getattr(self, "av_stream", None) is None:
             self.av_stream = torch.cuda.Stream()
         st = self.av_stream
-        for ev in events:
-            st.wait_event(ev)
         vp = C.c_void_p
         pitch = self.sol.s.pitch
-        a = (vp * n)(*[slot.rows[k].data_ptr() for k in range(n)])
-        b = (vp * n)(*[slot.rows[k].data_ptr() + 4 * pitch for k in range(n)])        # b + pitch floats = row 2
-        ini = (vp * n)(*[slot.init_dev.data_ptr() + 12 * k for k in range(n)])
-        tot = (vp * n)(*[slot.tot_dev.data_ptr() + 12 * k for k in range(n)])
+        a, b, ini, tot = [], [], [], []
+        for it in items:
+            for ev in it.events:
+                st.wait_event(ev)
+            for k in range(it.n):
+                rows = it.slot.rows[k].data_ptr()
+                a.append(rows)
+                b.append(rows + 4 * pitch)                       # b + pitch floats = row 2
+                ini.append(it.slot.init_dev.data_ptr() + 12 * k if it.use_init else None)
+                tot.append(it.slot.tot_dev.data_ptr() + 12 * k)
+        n = len(a)
         before = lib.slb_get_stream()
-        with torch.cuda.stream(st):
-            lib.slb_set_stream(st.cuda_stream)
-            try:
-                if use_init:
-                    slot.init_dev.copy_(slot.init, non_blocking=True)
-                rc = lib.slb_av_sums_exact_from_n(C.byref(self.sol.s.av_slab), n, a, b, ini if use_init else None, tot)
+        try:
+            with torch.cuda.stream(st):
+                lib.slb_set_stream(st.cuda_stream)
+                for it in items:
+                    if it.use_init:
+                        it.slot.init_dev.copy_(it.slot.init, non_blocking=True)
+                rc = lib.slb_av_sums_exact_from_n(C.byref(self.sol.s.av_slab), n, (vp * n)(*a), (vp * n)(*b),
+                                                  (vp * n)(*ini), (vp * n)(*tot))
                 if rc:
                     raise RuntimeError(f"slb_av_sums_exact_from_n -> {rc}")
-                if times is not None:
-                    for k, t in enumerate(times):
-                        rc = lib.slb_av_update_exact(slot.tot_dev.data_ptr() + 12 * k, av_data.data_ptr(), t)
+                for it in items:
+                    if not update:
+                        it.slot.tot.copy_(it.slot.tot_dev, non_blocking=True)
+                        continue
+                    for k, t in enumerate(it.times):
+                        rc = lib.slb_av_update_exact(it.slot.tot_dev.data_ptr() + 12 * k, av_data.data_ptr(), t)
                         if rc:
                             raise RuntimeError(f"slb_av_update_exact -> {rc}")
-                else:
-                    slot.tot.copy_(slot.tot_dev, non_blocking=True)
-            finally:
-                lib.slb_set_stream(before)
-            slot.done = torch.cuda.Event()
-            slot.done.record(st)
+                done = torch.cuda.Event()
+                done.record(st)
+                for it in items:
+                    it.slot.done = done
+        finally:
+            lib.slb_set_stream(before)
 
     def chain_done(self, slot, block):
         if block:
@@ -482,7 +493,7 @@ class ExactAvChain:
         av6 = chain.finish()
     """
 
-    def __init__(self, run, slots=16, lockstep=None):
+    def __init__(self, run, slots=32, lockstep=None, max_batch=4):
         self.run, self.eng = run, run.eng
         self.rank, self.world = run.rank, run.world
         # With halos staged through host memory (gloo rehearsals) an exchange blocks the host
@@ -497,6 +508,7 @@ class ExactAvChain:
             # few-byte host messages on a gloo group of their own, so that they are never
             # matched with halo messages between the same two ranks
             self.group = dist.new_group(backend="gloo")
+        self.max_batch = max_batch                     # iterations per launch of the sums: 2 lattices each, 8 per launch
         self.free = [self.eng.new_chain_slot() for _ in range(slots)]
         self.queue = collections.deque()
         self.av_data = self.eng.new_av_data()
@@ -517,6 +529,7 @@ class ExactAvChain:
             slot.rows = (slot.rows[1], slot.rows[0])
         item = _ChainSlot()
         item.slot, item.n, item.times, item.stage = slot, n, [float(t) for t in times], 0
+        item.use_init = not self.is_first
         item.events = self.run.rows_written()
         item.tag = self.seq
         self.seq += 1
@@ -538,22 +551,31 @@ class ExactAvChain:
 
     def _advance(self, block):
         """Move every queued iteration as far as it can go without waiting; with block, wait
-        for the oldest one to finish."""
-        launched_all_before = True
-        for k, it in enumerate(self.queue):
-            wait = block and k == 0
-            if it.stage == 0:                              # totals from the left slab not here yet
-                if not launched_all_before:
+        for the oldest one to finish.  Iterations whose start values are here go to the
+        device together, up to max_batch per launch (the sums of one lattice are a chain of
+        dependent passes that keeps three workgroups busy for about as long as a double step
+        keeps the whole device busy; the sums of several lattices side by side take no
+        longer): at once when nothing is running, else when a full batch has gathered."""
+        q = self.queue
+        ready = []
+        for it in q:
+            if it.stage != 0:
+                continue
+            if it.recv is not None:
+                if block and it is q[0]:
+                    it.recv.wait()
+                elif not it.recv.is_completed():
                     break
-                if it.recv is not None:
-                    if wait:
-                        it.recv.wait()
-                    elif not it.recv.is_completed():
-                        launched_all_before = False
-                        continue
-                self.eng.chain_launch(it.slot, it.n, it.recv is not None, it.events,
-                                      self.av_data, it.times if self.is_last else None)
+            ready.append(it)
+            if len(ready) == self.max_batch:
+                break
+        running = any(it.stage == 1 and not self.eng.chain_done(it.slot, False) for it in q)
+        if ready and (block or not running or len(ready) == self.max_batch):
+            self.eng.chain_launch(ready, self.av_data, self.is_last)
+            for it in ready:
                 it.stage = 1
+        for k, it in enumerate(q):
+            wait = block and k == 0
             if it.stage == 1:                              # sums running
                 if not self.eng.chain_done(it.slot, wait):
                     continue
@@ -567,8 +589,8 @@ class ExactAvChain:
                     it.send.wait()
                 if wait or it.send.is_completed():
                     it.stage = 3
-        while self.queue and self.queue[0].stage == 3:
-            self.free.append(self.queue.popleft().slot)
+        while q and q[0].stage == 3:
+            self.free.append(q.popleft().slot)
 
     def finish(self):
         """Wait for everything submitted; returns av_data (6 floats, numpy) on every rank."""

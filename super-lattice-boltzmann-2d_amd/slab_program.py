@@ -65,8 +65,9 @@ def main(argv):
     if rank == 0 and not quiet:
         print("# t_max = %0.20f" % t_max, flush=True)
 
-    if world > 1:
-        torch.cuda.set_stream(torch.cuda.Stream())    # not the legacy null stream (implicit synchronisation)
+    # not the legacy null stream: its implicit synchronisation would serialise the halo work
+    # and the sums of av(), which run on streams of their own, with the time loop
+    torch.cuda.set_stream(torch.cuda.Stream())
     L.slb_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
     tree = os.environ.get("SLB_AV") == "tree"
     L.slb_set_av_mode(slb.SLB_AV_TREE if tree else slb.SLB_AV_EXACT)
@@ -80,6 +81,11 @@ def main(argv):
         return E_omega > 0 and t >= t_start
 
     rows = (run.eng.new_rows(), run.eng.new_rows())
+    timing = os.environ.get("SLB_TIMING") is not None      # wall time of the time loop, on stderr
+    if timing:
+        import time
+        torch.cuda.synchronize()
+        w0, n_iter = time.perf_counter(), 0
     while True:
         t = np.float32(sol.s.t)                       # the engine's clock is the loop variable
         if not t < t_max:
@@ -107,6 +113,11 @@ def main(argv):
                 run.av(av_data, float(t))
     t = np.float32(sol.s.t)
     av6 = chain.finish() if chain is not None else av_data.cpu().numpy().copy()
+    if timing:
+        torch.cuda.synchronize()
+        sec, n_iter = time.perf_counter() - w0, int(sol.s.steps)
+        if rank == 0:
+            sys.stderr.write("# time loop: %d iterations in %.4f s (%.4f ms each)\n" % (n_iter, sec, 1e3 * sec / max(n_iter, 1)))
 
     # the three rows the record's sums read, put together on rank 0
     s = sol.s

@@ -186,7 +186,11 @@ class OracleEngine:
     def mark(self):
         return None
 
-    def chain_launch(self, slot, n, use_init, events, av_data, times):
+    def chain_launch(self, items, av_data, update):
+        for it in items:
+            self._chain_one(it.slot, it.n, it.use_init, av_data, it.times if update else None)
+
+    def _chain_one(self, slot, n, use_init, av_data, times):
         f = np.float32
         p = self.p
         dPhi, ymin = f(p.dPhi), f(p.PhiYmin)
