@@ -66,6 +66,29 @@ def test_program_display4_identical(solver_bin, oracle, tmp_path):
     assert "# t_max = " in g.stdout and "# norm=" in g.stdout
 
 
+def test_program_output_forms(solver_bin, oracle, tmp_path):
+    """o=+file appends to an existing file (reference: src/boltzmann_cli.c:171-173), o=stdout
+    writes the record between the log lines, and a file that cannot be opened ends the run
+    with the reference's message."""
+    args = ["display=4", "omega=100", "B=0.5", "n-harmonics=8", "g-grid=253", "t-max=0.01", "quiet=1"] + COMMON
+    for prog_dir in ("gpu", "orc"):
+        (tmp_path / prog_dir).mkdir()
+        (tmp_path / prog_dir / "log.txt").write_text("# kept line\n")
+    for e_dc in ("1", "1.25"):
+        a = [x for x in args if not x.startswith("E_dc=")] + ["E_dc=" + e_dc, "o=+log.txt"]
+        g = subprocess.run([solver_bin] + a, cwd=tmp_path / "gpu", capture_output=True, text=True, timeout=300)
+        assert g.returncode == 0, g.stdout + g.stderr
+        oracle.run_cli(a, cwd=tmp_path / "orc")
+    got, exp = (tmp_path / "gpu" / "log.txt").read_text(), (tmp_path / "orc" / "log.txt").read_text()
+    assert got == exp and got.startswith("# kept line\n") and len(got.splitlines()) == 7
+    g = subprocess.run([solver_bin] + args + ["o=stdout"], cwd=tmp_path / "gpu", capture_output=True, text=True, timeout=300)
+    assert g.returncode == 0, g.stdout + g.stderr
+    lines = g.stdout.splitlines()
+    assert all(l in lines for l in exp.splitlines()[1:4])          # the first record, on stdout this time
+    bad = subprocess.run([solver_bin] + args + ["o=no_such_dir/x.txt"], cwd=tmp_path / "gpu", capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and 'ERROR: Faled to open file "no_such_dir/x.txt" for writing.' in bad.stderr
+
+
 @pytest.mark.parametrize("tmax", ["0.012", "0.011"])     # averaging starts on the first / the second of a pair
 @pytest.mark.parametrize("env", [None, {"SLB_FORM": "fused"}, {"SLB_AV": "chain"}])
 def test_program_display4_wide_lattice_parallel_exact_sums(solver_bin, oracle, tmp_path, env, tmax):
