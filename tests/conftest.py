@@ -35,3 +35,23 @@ def solver_bin():
     if not os.path.exists(path):
         subprocess.run(["make", "-C", ROOT, "bin/boltzmann_solver"], check=True)
     return path
+
+
+@pytest.fixture(autouse=True)
+def _library_state_does_not_leak(request):
+    """After a GPU test the library launches on the null stream again, with default tuning
+    and exact sums, and torch's current stream is its default one: a test that leaves another
+    stream current would let later tests' copies race with the library's launches."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import torch
+    if not torch.cuda.is_available():
+        return
+    mod = importlib.import_module(PKG_NAME)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    L = mod.lib()
+    L.slb_set_stream(None)
+    L.slb_set_tuning(0, 0, 0)
+    L.slb_set_av_mode(mod.SLB_AV_EXACT)

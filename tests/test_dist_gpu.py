@@ -130,10 +130,8 @@ def _av_worker(rank, world, port, outdir, phys):
 def test_exact_av_over_slabs_on_one_gpu(world, phys, tmp_path):
     """av() with the running sums handed from slab to slab (HIP kernels, `world` processes on
     one GPU): av_data on every rank has the bits of the oracle's av() over the whole lattice."""
-    if world == 1:
-        _av_worker(0, 1, 0, str(tmp_path), phys)
-    else:
-        mp.spawn(_av_worker, args=(world, sh.free_port(), str(tmp_path), phys), nprocs=world, join=True)
+    # always in processes of their own: the worker makes a new stream the current one
+    mp.spawn(_av_worker, args=(world, sh.free_port(), str(tmp_path), phys), nprocs=world, join=True)
     av_ref = sh.reference_av_plan(ob, ob.make_params(**phys))
     for r in range(world):
         got = np.load(tmp_path / f"av{r}.npy")
