@@ -75,7 +75,9 @@ def main(argv):
     sol = run.eng.sol
     run.tiptoe()
     av_data = torch.zeros(6, dtype=torch.float32, device="cuda")
-    chain = None if tree else drv.ExactAvChain(run)
+    # SLB_AV_LOCKSTEP=0/1 overrides how the chain of running sums is driven (see ExactAvChain)
+    lockstep = os.environ.get("SLB_AV_LOCKSTEP")
+    chain = None if tree else drv.ExactAvChain(run, lockstep=None if lockstep is None else lockstep != "0")
 
     def averaged(t):
         return E_omega > 0 and t >= t_start

@@ -138,8 +138,8 @@ def test_exact_av_over_slabs_on_one_gpu(world, phys, tmp_path):
         assert np.array_equal(got.view(np.uint32), av_ref.view(np.uint32)), (r, got, av_ref)
 
 
-@pytest.mark.parametrize("world", [1, 3])
-def test_slab_program_writes_the_single_gpu_record(world, tmp_path, solver_bin):
+@pytest.mark.parametrize("world,lockstep", [(1, None), (3, None), (3, "0")])
+def test_slab_program_writes_the_single_gpu_record(world, lockstep, tmp_path, solver_bin):
     """slab_program.py (display=4 over slabs; here `world` processes on one GPU over gloo)
     writes the single-GPU program's record, every column to the last digit: the lattices are
     the same and the running sums of av() are handed from slab to slab."""
@@ -152,8 +152,12 @@ def test_slab_program_writes_the_single_gpu_record(world, tmp_path, solver_bin):
     script = os.path.join(sh.ROOT, sh.PKG, "slab_program.py")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(sh.free_port()), script] + args + ["o=slabs.txt"]
-    many = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600,
-                          env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
+    env = {**os.environ, "SLB_DIST_BACKEND": "gloo"}
+    if lockstep is not None:
+        # iterations left in flight, as over RCCL (the averaging period here has fewer
+        # iterations than the chain has slots, so no rank ever waits for a slot)
+        env["SLB_AV_LOCKSTEP"] = lockstep
+    many = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
     assert many.returncode == 0, many.stdout + many.stderr
     a, b = (tmp_path / "one.txt").read_text().splitlines(), (tmp_path / "slabs.txt").read_text().splitlines()
     assert a == b and len(a) == 3
