@@ -486,6 +486,9 @@ class ExactAvChain:
     here blocks the time loop: an iteration's rows wait in one of `slots` buffers until the
     totals from the left have arrived, and the loop only waits when it needs a buffer back.
 
+    torch's current stream has to be the library's launch stream (slb_set_stream), as in
+    slab_program.py: the events that order the sums after the steps are recorded on it.
+
         slot = chain.acquire()
         run.double_step(rows=slot.rows)
         chain.submit(slot, [t, t + dt])          # or [t] / only_second=True, see submit()
