@@ -294,9 +294,6 @@ void *slb_get_stream(void);
  *   slb_seq_sum: 41..47 = other workgroup shapes.
  * n_chunk = rows per workgroup in n (0: by lattice width), block = threads (0: 256). */
 void slb_set_tuning(int variant, int n_chunk, int block);
-/* rows per workgroup of the double step, for tuning: the first n_big chunks take `big` rows,
- * the rest `small` rows each (0, 0, 0: the library's choice) */
-void slb_set_row_split(int big, int n_big, int small);
 
 /* Library / device identification for logs: returns a static string. */
 const char *slb_version(void);

@@ -24,8 +24,6 @@ def main():
     ap.add_argument("--fused", action="store_true", help="time the one-launch step (variants 6, 7)")
     ap.add_argument("--double", action="store_true", help="time the double step (variants 21, 23, 25)")
     ap.add_argument("--multi", type=int, default=0, help="time the S-steps-per-launch kernel (S = 1..4)")
-    ap.add_argument("--splits", default="", help="double step: row splits big:n_big:small[,...] "
-                                                 "(the first n_big chunks take big rows, the rest small)")
     args = ap.parse_args()
     import torch
     slb = importlib.import_module("super-lattice-boltzmann-2d_amd")
@@ -54,16 +52,6 @@ def main():
                 ups = N * M / (ms * per_launch * 1e-3)
                 print(f"variant={v} n_chunk={nc:4d} block={b:4d}  {ms:8.4f} ms/launch  {gbs:8.1f} GB/s  "
                       f"{gbs / 80.0:5.1f}% of 8 TB/s  {ups:.3e} updates/s", flush=True)
-    L.slb_set_row_split.argtypes = [__import__("ctypes").c_int] * 3
-    for sp in [x for x in args.splits.split(",") if x]:
-        big, n_big, small = (int(x) for x in sp.split(":"))
-        L.slb_set_tuning(0, 0, 0)
-        L.slb_set_row_split(big, n_big, small)
-        sol.run_timed(4)
-        ms = min(sol.run_timed(args.steps) for _ in range(3)) / (per_launch * args.steps)
-        ups = N * M / (ms * per_launch * 1e-3)
-        print(f"split {big:3d} x{n_big} then {small:3d}  {ms:8.4f} ms/launch  {ups:.3e} updates/s", flush=True)
-    L.slb_set_row_split(0, 0, 0)
     sol.close()
 
 

@@ -27,7 +27,7 @@ ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "Handle
                  "slb_av_sums_exact", "slb_av_sums_exact_n", "slb_av_sums_exact_from_n", "slb_av_update_exact", "slb_halo_pack", "slb_halo_unpack", "slb_halo_pack_segs", "slb_halo_unpack_segs", "slb_av_partial",
                  "slb_frame_values", "slb_seq_sum", "slb_seq_sum_stats",
                  "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream",
-                 "slb_set_tuning", "slb_set_row_split", "slb_version")
+                 "slb_set_tuning", "slb_version")
 ABI_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha",
                "PhiYmin", "PhiYmax", "host_B", "t_start", "host_dPhi", "host_dt",
                "host_bdt", "host_nu_tilde", "host_nu2", "host_nu",

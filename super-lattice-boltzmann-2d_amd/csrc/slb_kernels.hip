@@ -37,7 +37,6 @@ Physics     g_phys = {};
 hipStream_t g_stream = nullptr;
 int         g_av_mode = SLB_AV_EXACT;
 int         g_variant = 0, g_n_chunk = 0, g_block = 0;
-int         g_split_big = 0, g_split_n_big = 0, g_split_small = 0;   // slb_set_row_split
 double     *g_ws = nullptr;          // reduction workspace, allocated once
 int         g_ws_device = -1;
 constexpr int kMaxAvBlocks = 1024;
@@ -615,10 +614,6 @@ struct Fused2Args {
   float E_dc, E_omega, B, dt, dPhi, PhiYmin, nu, nu2, nu_tilde, bdt;
   float c[8];                                // cosines: stage A 0,1  B 2,3  C 4,5  D 6,7
   int N, pitch, m_offset, n_chunk, jj0;
-  // rows per workgroup: the first n_big chunks take `n_chunk` rows each, the others `n_small`
-  // (workgroups are dispatched chunk after chunk, so the short ones come last and fill the
-  // end of the launch, when the long ones would leave compute units idle)
-  int n_big, n_small;
   int jf[4], jl[4];                          // columns stage A, B, C, D produce
 };
 
@@ -648,10 +643,8 @@ fused2_step_kernel(const Fused2Args p)
   const int jcl = jj < 0 ? 0 : (jj > p.pitch - V ? p.pitch - V : jj);
   const unsigned j = (unsigned)jcl;
 
-  const int y  = blockIdx.y;
-  const int n0 = y < p.n_big ? y * p.n_chunk : p.n_big * p.n_chunk + (y - p.n_big) * p.n_small;
-  const int len = y < p.n_big ? p.n_chunk : p.n_small;
-  const int n1 = n0 + len < p.N ? n0 + len : p.N;
+  const int n0 = blockIdx.y * p.n_chunk;
+  const int n1 = n0 + p.n_chunk < p.N ? n0 + p.n_chunk : p.N;
   // first row each stage has to form so that D can form rows n0..n1-1
   const int c_lo = n0 > 1 ? n0 - 1 : 0, b_lo = n0 > 2 ? n0 - 2 : 0, a_lo = n0 > 3 ? n0 - 3 : 0;
   const int r_end = n1 + 2;                      // D forms row n1-1 when A stands at n1+2
@@ -1602,8 +1595,7 @@ int launch_fused2(Fused2Args &args, int block)
   const int per_wave = 62 * 4;
   const int waves = (hi + 1 - args.jj0 + per_wave - 1) / per_wave;
   const int wpb = block / 64;
-  const int rest = args.N - args.n_big * args.n_chunk;            // rows left to the short chunks
-  dim3 grid((waves + wpb - 1) / wpb, args.n_big + (rest + args.n_small - 1) / args.n_small);
+  dim3 grid((waves + wpb - 1) / wpb, (args.N + args.n_chunk - 1) / args.n_chunk);
   hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS>), grid, dim3(block), 0, g_stream, args);
   return (int)hipGetLastError();
 }
@@ -1667,10 +1659,6 @@ void slb_set_stream(void *s)           { g_stream = (hipStream_t)s; }
 void *slb_get_stream(void)             { return (void *)g_stream; }
 void slb_set_av_mode(int mode)         { g_av_mode = (mode == SLB_AV_TREE || mode == SLB_AV_CHAIN) ? mode : SLB_AV_EXACT; }
 void slb_set_tuning(int v, int nc, int b) { g_variant = v; g_n_chunk = nc; g_block = b; }
-void slb_set_row_split(int big, int n_big, int small)
-{
-  g_split_big = big; g_split_n_big = n_big; g_split_small = small;
-}
 const char *slb_version(void)          { return "slb2d-gfx950 0.1"; }
 
 int slb_sweep(const slb_slab *slab,
@@ -1856,10 +1844,6 @@ int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
   }
   if (n_chunk > s.N) n_chunk = s.N;
   s.n_chunk = n_chunk;
-  s.n_big = 0; s.n_small = n_chunk;                   // all chunks alike
-  if (g_split_big > 0 && g_split_small > 0 && g_split_n_big >= 0 && g_split_n_big * g_split_big < s.N) {
-    s.n_chunk = g_split_big; s.n_big = g_split_n_big; s.n_small = g_split_small;
-  }
   if (rows_first) return launch_fused2<3, false, true>(s, block);
   switch (g_variant) {
     case 21: return launch_fused2<2>(s, block);           // register budget of 2, 3 (default), 4 waves per SIMD
