@@ -50,7 +50,8 @@ def _worker(rank, world, port, outdir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "sweeps"), (3, "sweeps"), (2, "fused"), (3, "fused"), (2, "double"), (3, "double"), (3, "mixed")])
+@pytest.mark.parametrize("world,mode", [(2, "sweeps"), (3, "sweeps"), (2, "fused"), (3, "fused"), (2, "double"), (3, "double"), (3, "mixed"),
+                                        (4, "mixed"), (8, "double")])      # 8 slabs of 12-13 columns
 def test_slab_driver_matches_single_domain(world, mode, tmp_path):
     mp.spawn(_worker, args=(world, sh.free_port(), str(tmp_path), mode), nprocs=world, join=True)
     p = ob.make_params(**PHYS)
@@ -84,7 +85,7 @@ def _av_worker(rank, world, port, outdir, lockstep):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,lockstep", [(1, False), (2, False), (3, False), (3, True)])
+@pytest.mark.parametrize("world,lockstep", [(1, False), (2, False), (3, False), (3, True), (8, False)])
 def test_exact_av_chain_over_slabs_has_the_single_domain_bits(world, lockstep, tmp_path):
     """The running sums of av() handed from slab to slab: av_data on every rank equals the
     oracle's av() over the whole lattice, bit for bit, whatever mix of steps fed it."""
