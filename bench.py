@@ -113,7 +113,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
         else:
             dist.init_process_group(backend)
 
