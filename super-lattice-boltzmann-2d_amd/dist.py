@@ -496,7 +496,7 @@ class ExactAvChain:
         av6 = chain.finish()
     """
 
-    def __init__(self, run, slots=32, lockstep=None, max_batch=4):
+    def __init__(self, run, slots=48, lockstep=None, max_batch=4):
         self.run, self.eng = run, run.eng
         self.rank, self.world = run.rank, run.world
         # With halos staged through host memory (gloo rehearsals) an exchange blocks the host
@@ -512,6 +512,10 @@ class ExactAvChain:
             # matched with halo messages between the same two ranks
             self.group = dist.new_group(backend="gloo")
         self.max_batch = max_batch                     # iterations per launch of the sums: 2 lattices each, 8 per launch
+        # slots: a hop of the chain takes one launch of the sums (about 2 ms next to the time
+        # loop) plus the wait for the next poll (one double step, about 1.1 ms); eight slabs
+        # are then some twenty double steps behind rank 0, which 48 buffers (25 MB each at
+        # 2^20 columns) cover with room to spare
         self.free = [self.eng.new_chain_slot() for _ in range(slots)]
         self.queue = collections.deque()
         self.av_data = self.eng.new_av_data()
