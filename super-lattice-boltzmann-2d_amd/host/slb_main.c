@@ -172,20 +172,25 @@ static int write_strobe(FILE *f, slb_solver *s, float *strobe, const float *a0ro
 /* av() beside the time loop.  The sums need three rows of the main lattice a step has
  * written (a rows 0 and 1, b row 1).  Those rows go into a slot of a small ring -- written
  * by the double-step kernel itself for both of its iterations, or copied after a single
- * step -- so that the time loop never has to wait for the sums: each step's sums run on one
- * of a few streams of their own (the exact-order sums keep three compute units busy for
- * about as long as a step keeps all of them busy, and the sums of different steps do not
- * depend on each other), and one more stream applies the running-average updates in step
- * order.  A slot is reused only after its update is done. */
+ * step -- so that the time loop never has to wait for the sums.  The exact-order sums of one
+ * lattice are a chain of dependent passes that keeps three workgroups busy for about as long
+ * as a double step keeps the whole device busy; the sums of several lattices side by side
+ * take no longer, and the sums of different steps do not depend on each other.  So the rows
+ * of up to four double steps wait until the stream of the sums is idle (or eight lattices
+ * have gathered) and then go in ONE launch, followed on the same stream by the
+ * running-average updates in step order.  A slot is reused only after its update is done.
+ * (The tree sums are short: they go out at once.) */
 #define AV_SLOTS       32
-#define AV_SUM_STREAMS 16
-static struct { float *rows, *tot; double *sums; hipEvent_t ev_sums, ev_upd; int used; } av_slot[AV_SLOTS];
-static hipStream_t av_sum_stream[AV_SUM_STREAMS], av_upd_stream;
-static int         av_streams = 3;            /* sum streams in use (SLB_AV_STREAMS=1..16) */
+static struct { float *rows, *tot; double *sums; hipEvent_t ev_upd; int used; } av_slot[AV_SLOTS];
+static hipStream_t av_sum_stream;                  /* sums, and the updates behind them */
 static hipEvent_t  ev_rows;
 static long        av_index = 0;
 static int         av_tree = 0;
 static slb_slab    av_cols;
+#define AV_BATCH 8                               /* lattices per launch of the exact sums */
+static struct { int slot; float t; } av_pending[AV_BATCH];
+static int         av_n_pending = 0, av_batch_out = 0;
+static hipEvent_t  ev_batch;                     /* end of the last launch of the sums + updates */
 
 static void av_ring_init(const slb_solver *s)
 {
@@ -195,55 +200,88 @@ static void av_ring_init(const slb_solver *s)
     HIP_OK(hipMemset(av_slot[k].rows, 0, 3 * row_bytes));
     HIP_OK(hipMalloc((void **)&av_slot[k].tot, 4 * sizeof(float)));
     HIP_OK(hipMalloc((void **)&av_slot[k].sums, 4 * sizeof(double)));
-    HIP_OK(hipEventCreateWithFlags(&av_slot[k].ev_sums, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&av_slot[k].ev_upd, hipEventDisableTiming));
     av_slot[k].used = 0;
   }
-  for (int k = 0; k < AV_SUM_STREAMS; k++)
-    HIP_OK(hipStreamCreateWithFlags(&av_sum_stream[k], hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&av_upd_stream, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&av_sum_stream, hipStreamNonBlocking));
   HIP_OK(hipEventCreateWithFlags(&ev_rows, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&ev_batch, hipEventDisableTiming));
   /* columns 1..M, i.e. m < TMSIZE (reference: src/boltzmann_c_solver.c:417) */
   av_cols.pitch = s->pitch; av_cols.m_offset = 0; av_cols.j_first = 1; av_cols.j_last = host_TMSIZE - 1;
 }
 
 /* the slot the av() number av_index + ahead will use; the time loop's stream waits until
  * the slot's previous occupant has been summed and applied */
-static float *av_ring_acquire(int ahead)
+static void av_ring_flush(slb_solver *s);
+
+static float *av_ring_acquire(slb_solver *s, int ahead)
 {
   const int k = (int)((av_index + ahead) % AV_SLOTS);
+  for (int i = 0; i < av_n_pending; i++)
+    if (av_pending[i].slot == k) { av_ring_flush(s); break; }     /* its rows are still waiting to be summed */
   if (av_slot[k].used) HIP_OK(hipStreamWaitEvent(NULL, av_slot[k].ev_upd, 0));
   return av_slot[k].rows;
+}
+
+/* exact sums: everything that is waiting goes to the device in one launch, updates behind it */
+static void av_ring_flush(slb_solver *s)
+{
+  if (av_n_pending == 0) return;
+  hipStream_t st = av_sum_stream;
+  const float *a[AV_BATCH], *b[AV_BATCH];
+  float *tot[AV_BATCH];
+  for (int i = 0; i < av_n_pending; i++) {
+    const int k = av_pending[i].slot;
+    a[i] = av_slot[k].rows; b[i] = a[i] + s->pitch; tot[i] = av_slot[k].tot;
+  }
+  HIP_OK(hipEventRecord(ev_rows, NULL));
+  HIP_OK(hipStreamWaitEvent(st, ev_rows, 0));
+  slb_set_stream(st);
+  int rc = slb_av_sums_exact_n(&av_cols, av_n_pending, a, b, tot);
+  if (rc != 0) { fprintf(stderr, "ERROR: av sums failed (%d)\n", rc); exit(EXIT_FAILURE); }
+  for (int i = 0; i < av_n_pending && rc == 0; i++) {
+    const int k = av_pending[i].slot;
+    rc = slb_av_update_exact(av_slot[k].tot, s->av_data, av_pending[i].t);
+    HIP_OK(hipEventRecord(av_slot[k].ev_upd, st));
+    av_slot[k].used = 1;
+  }
+  if (rc != 0) { fprintf(stderr, "ERROR: av update failed (%d)\n", rc); exit(EXIT_FAILURE); }
+  HIP_OK(hipEventRecord(ev_batch, st));
+  av_batch_out = 1;
+  slb_set_stream(NULL);
+  av_n_pending = 0;
 }
 
 /* the next n (1 or 2) slots' rows have been queued on the time loop's stream: queue their
  * sums (one launch) and their updates of av_data for the loop times t[0..n-1] */
 static void av_ring_submit(slb_solver *s, int n, const float *t)
 {
-  hipStream_t st = av_sum_stream[av_tree ? 0 : (av_index / 2) % av_streams];   /* the tree sums share a workspace */
-  const float *a[2], *b[2];
-  float *tot[2];
-  int slot[2] = {0, 0}, rc = 0;
-  for (int i = 0; i < n; i++) {
-    slot[i] = (int)((av_index + i) % AV_SLOTS);
-    a[i] = av_slot[slot[i]].rows; b[i] = a[i] + s->pitch; tot[i] = av_slot[slot[i]].tot;
+  if (!av_tree) {
+    for (int i = 0; i < n; i++) {
+      av_pending[av_n_pending].slot = (int)((av_index + i) % AV_SLOTS);
+      av_pending[av_n_pending].t = t[i];
+      av_n_pending++;
+    }
+    av_index += n;
+    /* out at once when nothing is running; otherwise when a full launch has gathered (two
+     * more lattices would not fit) */
+    if (av_n_pending + 2 > AV_BATCH || !av_batch_out || hipEventQuery(ev_batch) == hipSuccess) av_ring_flush(s);
+    return;
   }
+  /* tree sums: short launches that share a workspace; sums and update of each step in turn */
+  hipStream_t st = av_sum_stream;
+  int rc = 0;
   HIP_OK(hipEventRecord(ev_rows, NULL));
   HIP_OK(hipStreamWaitEvent(st, ev_rows, 0));
   slb_set_stream(st);
-  if (av_tree) for (int i = 0; i < n && rc == 0; i++) rc = slb_av_partial(&av_cols, a[i], b[i], av_slot[slot[i]].sums);
-  else         rc = slb_av_sums_exact_n(&av_cols, n, a, b, tot);
-  if (rc != 0) { fprintf(stderr, "ERROR: av sums failed (%d)\n", rc); exit(EXIT_FAILURE); }
-  HIP_OK(hipEventRecord(av_slot[slot[0]].ev_sums, st));
-  HIP_OK(hipStreamWaitEvent(av_upd_stream, av_slot[slot[0]].ev_sums, 0));
-  slb_set_stream(av_upd_stream);
   for (int i = 0; i < n && rc == 0; i++) {
-    rc = av_tree ? slb_av_update(av_slot[slot[i]].sums, s->av_data, t[i])
-                 : slb_av_update_exact(av_slot[slot[i]].tot, s->av_data, t[i]);
-    HIP_OK(hipEventRecord(av_slot[slot[i]].ev_upd, av_upd_stream));
-    av_slot[slot[i]].used = 1;
+    const int k = (int)((av_index + i) % AV_SLOTS);
+    rc = slb_av_partial(&av_cols, av_slot[k].rows, av_slot[k].rows + s->pitch, av_slot[k].sums);
+    if (rc == 0) rc = slb_av_update(av_slot[k].sums, s->av_data, t[i]);
+    HIP_OK(hipEventRecord(av_slot[k].ev_upd, st));
+    av_slot[k].used = 1;
   }
-  if (rc != 0) { fprintf(stderr, "ERROR: av update failed (%d)\n", rc); exit(EXIT_FAILURE); }
+  if (rc != 0) { fprintf(stderr, "ERROR: av sums failed (%d)\n", rc); exit(EXIT_FAILURE); }
   slb_set_stream(NULL);
   av_index += n;
 }
@@ -252,16 +290,17 @@ static void av_ring_submit(slb_solver *s, int n, const float *t)
 static void av_ring_copy_and_submit(slb_solver *s, float t)
 {
   const size_t row_bytes = sizeof(float) * (size_t)s->pitch;
-  float *rows = av_ring_acquire(0);
+  float *rows = av_ring_acquire(s, 0);
   HIP_OK(hipMemcpyAsync(rows, s->a[s->next], 2 * row_bytes, hipMemcpyDeviceToDevice, NULL));
   HIP_OK(hipMemcpyAsync(rows + 2 * (size_t)s->pitch, s->b[s->next] + s->pitch, row_bytes,
                         hipMemcpyDeviceToDevice, NULL));
   av_ring_submit(s, 1, &t);
 }
 
-static void av_ring_drain(void)
+static void av_ring_drain(slb_solver *s)
 {
-  HIP_OK(hipStreamSynchronize(av_upd_stream));      /* updates are in step order: the last one ends it all */
+  av_ring_flush(s);
+  HIP_OK(hipStreamSynchronize(av_sum_stream));      /* one stream, updates in step order */
   for (int k = 0; k < AV_SLOTS; k++) av_slot[k].used = 0;
 }
 
@@ -285,7 +324,6 @@ void slb_close_output(void)
 int slb_main(int argc, char **argv)
 {
   parse_cmd(argc, argv);
-  av_streams = 3;
   HIP_OK(hipSetDevice(device));
 
   float T = host_omega > 0 ? (2 * SLB_PI / host_omega) : 0;   /* period of the a/c field */
@@ -323,10 +361,6 @@ int slb_main(int argc, char **argv)
    * SLB_AV=chain: the exact sums by one lane adding term after term (cross-check) */
   const char *avm = getenv("SLB_AV");
   av_tree = avm != NULL && strcmp(avm, "tree") == 0;
-  if (getenv("SLB_AV_STREAMS") != NULL) {
-    av_streams = atoi(getenv("SLB_AV_STREAMS"));
-    av_streams = av_streams < 1 ? 1 : (av_streams > AV_SUM_STREAMS ? AV_SUM_STREAMS : av_streams);
-  }
   slb_set_av_mode(av_tree ? SLB_AV_TREE :
                   avm != NULL && strcmp(avm, "chain") == 0 ? SLB_AV_CHAIN : SLB_AV_EXACT);
 
@@ -356,7 +390,7 @@ int slb_main(int argc, char **argv)
           } else {
             /* av() after both iterations, or only after the second when t_start falls
              * between them (the first iteration's rows then land in a slot nobody reads) */
-            float *ra = av_ring_acquire(0), *rb = av_ring_acquire(1);
+            float *ra = av_ring_acquire(s, 0), *rb = av_ring_acquire(s, 1);
             slb_solver_double_step_rows(s, k1 ? ra : rb, k1 ? rb : ra);
             const float tt[2] = {k1 ? t : t2, t2};
             av_ring_submit(s, k1 + k2, tt);
@@ -383,7 +417,7 @@ int slb_main(int argc, char **argv)
       }
 
       if (host_E_omega > 0 && display == 77 && frame_time >= 0.01) {
-        av_ring_drain();
+        av_ring_drain(s);
         av(0, s->a[s->next], s->b[s->next], s->av_data, t);
         slb_solver_get_rows(s, 1 + s->current, 0, 3, a_rows);
         slb_solver_get_rows(s, 5 + s->current, 1, 2, b_rows);
@@ -438,7 +472,7 @@ int slb_main(int argc, char **argv)
       frame_time += host_dt;
     }
 
-    av_ring_drain();
+    av_ring_drain(s);
     if (timing) {
       HIP_OK(hipDeviceSynchronize());
       clock_gettime(CLOCK_MONOTONIC, &w1);
