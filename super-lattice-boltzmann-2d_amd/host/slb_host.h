@@ -179,6 +179,9 @@ void slb_host_multipliers(float k3[3]);
  * a01 = rows 0 and 1 of a, b1 = row 1 of b (row pitch `pitch`), av6 = averaging data
  * (rescaled in place), T = period of the a/c field; and the closing of `out` */
 void slb_write_display4(float norm, const float *a01, const float *b1, int pitch, float *av6, float T);
+/* one display=77 record (reference: src/boltzmann_c_solver.c:298-331): a012 = rows 0..2 of a,
+ * b12 = rows 1..2 of b of the lattice BEFORE the step just taken, av6 rescaled in place */
+void slb_write_display77(float norm, const float *a012, const float *b12, int pitch, float *av6, float t);
 void slb_close_output(void);
 
 /* the whole program behind main() */

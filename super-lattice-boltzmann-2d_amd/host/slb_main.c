@@ -40,7 +40,7 @@ static void scale_av(float *av6, const float k3[3], float period)
 }
 
 /* one display=77 record (reference: src/boltzmann_c_solver.c:298-331) */
-static void write_frame77(float norm, const float *a012, const float *b12, int pitch,
+void slb_write_display77(float norm, const float *a012, const float *b12, int pitch,
                           float *av6, float t)
 {
   printf("\n# t=%0.20f norm=%0.20f\n", t, norm);
@@ -423,7 +423,7 @@ int slb_main(int argc, char **argv)
         slb_solver_get_rows(s, 5 + s->current, 1, 2, b_rows);
         HIP_OK(hipMemcpy(av6, s->av_data, sizeof(av6), hipMemcpyDeviceToHost));
         const float norm = slb_host_norm(a_rows, host_M, host_dPhi, host_alpha);
-        write_frame77(norm, a_rows, b_rows, pitch, av6, t);
+        slb_write_display77(norm, a_rows, b_rows, pitch, av6, t);
         /* the CPU solver rescales its averaging data in place at every record */
         HIP_OK(hipMemcpy(s->av_data, av6, sizeof(av6), hipMemcpyHostToDevice));
         frame_time = 0;

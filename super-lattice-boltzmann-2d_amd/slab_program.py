@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""display=4 runs of the boltzmann_solver program over phi_y slabs, one process per GPU.
+"""display=4 and display=77 runs of the boltzmann_solver program over phi_y slabs, one process per GPU.
 
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 \\
         super-lattice-boltzmann-2d_amd/slab_program.py display=4 E_dc=1 ... g-grid=8388608 o=out.txt
 
-Same name=value parameters (read by the same C parser) and the same display=4 record as
-the single-GPU program (reference: src/boltzmann_solver.c:74-401).  The lattices are
+Same name=value parameters (read by the same C parser) and the same display=4 record /
+display=77 trace as the single-GPU program (reference: src/boltzmann_solver.c:74-401,
+src/boltzmann_c_solver.c:180-187, 298-331).  The lattices are
 bit-identical to a single-GPU run; the instantaneous sums and the norm are formed on
 rank 0 from the three rows they need, in the reference's order, so those columns are
 bit-identical too.  The period averages come from av() over slabs with the running sums
@@ -51,9 +52,10 @@ def main(argv):
     cargs = (C.c_char_p * (len(args) + 2))(b"boltzmann_solver", *[a.encode() for a in args], None)
     L.parse_cmd.argtypes, L.parse_cmd.restype = [C.c_int, C.POINTER(C.c_char_p)], None
     L.parse_cmd(len(args) + 1, cargs)
-    if C.c_int.in_dll(L, "display").value != 4:
+    display = C.c_int.in_dll(L, "display").value
+    if display not in (4, 77):
         if rank == 0:
-            sys.stderr.write("ERROR: the slab program writes display=4 records only.\n")
+            sys.stderr.write("ERROR: the slab program writes display=4 records and display=77 traces only.\n")
         return 1
     L.slb_derive_and_load()
     g = slb.get_global
@@ -82,19 +84,74 @@ def main(argv):
     def averaged(t):
         return E_omega > 0 and t >= t_start
 
+    def kind(t, ft):
+        """What follows the step taken at loop time t: 0 nothing, 1 av(), 2 a display=77 record."""
+        if display == 77:
+            return 2 if E_omega > 0 and np.float64(ft) >= 0.01 else 0
+        return 1 if averaged(t) else 0
+
+    fp = C.c_void_p
+    L.slb_host_norm.argtypes, L.slb_host_norm.restype = [fp, C.c_int, C.c_float, C.c_float], C.c_float
+    M = g("host_M")
+
+    def gather_rows(arr_a, arr_b, na, nb0, nb):
+        """rows 0..na-1 of a-array arr_a and rows nb0..nb0+nb-1 of b-array arr_b over all slabs,
+        on rank 0 as (na, M+3) and (nb, M+3) arrays (None elsewhere)"""
+        s = sol.s
+        torch.cuda.synchronize()
+        ra, rb = sol.rows(arr_a, 0, na), sol.rows(arr_b, nb0, nb)
+        lo = s.G - 1 if rank == 0 else s.G
+        hi = s.G + s.W + 2 if rank == world - 1 else s.G + s.W
+        piece = (np.ascontiguousarray(ra[:, lo:hi]), np.ascontiguousarray(rb[:, lo:hi]))
+        pieces = [piece]
+        if world > 1:
+            pieces = [None] * world if rank == 0 else None
+            dist.gather_object(piece, pieces, dst=0)
+        if rank != 0:
+            return None, None
+        a_rows = np.ascontiguousarray(np.concatenate([p[0] for p in pieces], axis=1))
+        b_rows = np.ascontiguousarray(np.concatenate([p[1] for p in pieces], axis=1))
+        assert a_rows.shape == (na, M + 3) and b_rows.shape == (nb, M + 3)
+        return a_rows, b_rows
+
+    def record77(t):
+        """av() of the lattice the step wrote, then the record from the lattice before it
+        (reference: src/boltzmann_c_solver.c:180-187); the averaging data come back rescaled."""
+        if chain is not None:
+            chain.submit_current(t)
+            av6 = chain.finish()
+        else:
+            run.av(av_data, float(t))
+            av6 = av_data.cpu().numpy().copy()
+        s = sol.s
+        a012, b12 = gather_rows(1 + s.next, 5 + s.next, 3, 1, 2)      # after the swap `next` is the old lattice
+        if rank == 0:
+            L.slb_write_display77.argtypes = [C.c_float, fp, fp, C.c_int, fp, C.c_float]
+            L.slb_write_display77.restype = None
+            norm = L.slb_host_norm(a012.ctypes.data, M, g("host_dPhi"), g("host_alpha"))
+            L.slb_write_display77(norm, a012.ctypes.data, b12.ctypes.data, M + 3, av6.ctypes.data, float(t))
+        if world > 1:
+            box = [av6]
+            dist.broadcast_object_list(box, src=0)
+            av6 = box[0]
+        (chain.av_data if chain is not None else av_data).copy_(torch.from_numpy(np.ascontiguousarray(av6)))
+
     rows = (run.eng.new_rows(), run.eng.new_rows())
     timing = os.environ.get("SLB_TIMING") is not None      # wall time of the time loop, on stderr
     if timing:
         import time
         torch.cuda.synchronize()
         w0, n_iter = time.perf_counter(), 0
+    frame_time = np.float32(0)
     while True:
         t = np.float32(sol.s.t)                       # the engine's clock is the loop variable
         if not t < t_max:
             break
-        t2 = np.float32(t + dt)
-        if t2 < t_max and averaged(t) == averaged(t2):
-            if averaged(t):
+        t2, ft2 = np.float32(t + dt), np.float32(frame_time + dt)
+        k1, k2 = kind(t, frame_time), kind(t2, ft2)
+        if t2 < t_max and k1 == k2 and k1 < 2:
+            frame_time = np.float32(ft2 + dt)
+            if k1 == 1:
                 # two iterations per launch; the launch also hands out the rows av() reads of both
                 if chain is not None:
                     slot = chain.acquire()
@@ -108,11 +165,15 @@ def main(argv):
                 run.double_step()
             continue
         run.step_fused()
-        if averaged(t):
+        if k1 == 2:
+            record77(t)
+            frame_time = np.float32(0)
+        elif k1 == 1:
             if chain is not None:
                 chain.submit_current(t)
             else:
                 run.av(av_data, float(t))
+        frame_time = np.float32(frame_time + dt)
     t = np.float32(sol.s.t)
     av6 = chain.finish() if chain is not None else av_data.cpu().numpy().copy()
     if timing:
@@ -121,32 +182,19 @@ def main(argv):
         if rank == 0:
             sys.stderr.write("# time loop: %d iterations in %.4f s (%.4f ms each)\n" % (n_iter, sec, 1e3 * sec / max(n_iter, 1)))
 
-    # the three rows the record's sums read, put together on rank 0
-    s = sol.s
-    torch.cuda.synchronize()
-    a01 = sol.rows(1 + s.current, 0, 2)
-    b1 = sol.rows(5 + s.current, 1, 1)
-    lo = s.G - 1 if rank == 0 else s.G
-    hi = s.G + s.W + 2 if rank == world - 1 else s.G + s.W
-    piece = (np.ascontiguousarray(a01[:, lo:hi]), np.ascontiguousarray(b1[:, lo:hi]))
-    pieces = [piece]
-    if world > 1:
-        pieces = [None] * world if rank == 0 else None
-        dist.gather_object(piece, pieces, dst=0)
-    rc = 0
+    # display=4: the three rows the record's sums read, put together on rank 0
+    if display == 4:
+        s = sol.s
+        a_rows, b_row = gather_rows(1 + s.current, 5 + s.current, 2, 1, 1)
+        if rank == 0:
+            L.slb_write_display4.argtypes = [C.c_float, fp, fp, C.c_int, fp, C.c_float]
+            L.slb_write_display4.restype = None
+            norm = L.slb_host_norm(a_rows.ctypes.data, M, g("host_dPhi"), g("host_alpha"))
+            L.slb_write_display4(norm, a_rows.ctypes.data, b_row.ctypes.data, M + 3, av6.ctypes.data, float(T))
     if rank == 0:
-        M = g("host_M")
-        a_rows = np.ascontiguousarray(np.concatenate([p[0] for p in pieces], axis=1))
-        b_row = np.ascontiguousarray(np.concatenate([p[1] for p in pieces], axis=1))
-        assert a_rows.shape == (2, M + 3) and b_row.shape == (1, M + 3)
-        fp = C.c_void_p
-        L.slb_host_norm.argtypes, L.slb_host_norm.restype = [fp, C.c_int, C.c_float, C.c_float], C.c_float
-        L.slb_write_display4.argtypes = [C.c_float, fp, fp, C.c_int, fp, C.c_float]
-        L.slb_write_display4.restype = None
-        norm = L.slb_host_norm(a_rows.ctypes.data, M, g("host_dPhi"), g("host_alpha"))
-        L.slb_write_display4(norm, a_rows.ctypes.data, b_row.ctypes.data, M + 3, av6.ctypes.data, float(T))
         L.slb_close_output.argtypes, L.slb_close_output.restype = [], None
         L.slb_close_output()
+    rc = 0
     run.close()
     if world > 1:
         dist.barrier()

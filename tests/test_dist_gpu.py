@@ -164,6 +164,29 @@ def test_slab_program_writes_the_single_gpu_record(world, lockstep, tmp_path, so
 
 
 @pytest.mark.parametrize("world", [1, 3])
+def test_slab_program_display77_trace(world, tmp_path, solver_bin):
+    """display=77 over slabs: every record of the trace (sums over the CPU solver's flat index,
+    averaging data rescaled in place at each record) equals the single-GPU program's."""
+    import subprocess
+    args = ["display=77", "E_dc=1", "E_omega=0.1", "omega=100", "mu=5", "alpha=1", "B=0.5", "PhiYmin=-4",
+            "PhiYmax=4", "dt=0.001", "n-harmonics=16", "g-grid=4001", "t-max=0.05", "quiet=1"]
+    one = subprocess.run([solver_bin] + args + ["o=one.txt"], cwd=tmp_path, capture_output=True, text=True,
+                         timeout=300)
+    assert one.returncode == 0, one.stdout + one.stderr
+    script = os.path.join(sh.ROOT, sh.PKG, "slab_program.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(sh.free_port()), script] + args + ["o=slabs.txt"]
+    many = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=300,
+                          env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
+    assert many.returncode == 0, many.stdout + many.stderr
+    a, b = (tmp_path / "one.txt").read_text().splitlines(), (tmp_path / "slabs.txt").read_text().splitlines()
+    assert len(a) == 22                          # 11 records of header + data
+    assert a == b
+    pick = lambda s: [l for l in s.splitlines() if l.startswith("# t=")]
+    assert pick(one.stdout) == pick(many.stdout)
+
+
+@pytest.mark.parametrize("world", [1, 3])
 def test_slab_program_with_tree_sums(world, tmp_path, solver_bin):
     """The same with SLB_AV=tree (per-slab sums in double, all-reduced): the instantaneous
     columns and the norm are the single-GPU program's to the last digit, the period averages
