@@ -42,6 +42,8 @@ def _check_step_on_window(sol, slb, oracle, p, c0, c1):
     (128, 1 << 20, 3),       # config 3
     (512, 1 << 20, 2),       # config 5: harmonic-heavy, I_n underflows to 0 for large n
     (128, 1 << 23, 2),       # config 4 on a single GPU (39 GB)
+    (256, 1 << 20, 2),       # between the named shapes: another row-chunk length
+    (130, 300001, 2),        # odd sizes: partial last chunk, ragged last strip
 ])
 def test_full_shape_windows_bit_exact(slb, oracle, N, M, steps):
     p = oracle.make_params(N=N, M=M, B=4000.0 / M, omega=100.0)
@@ -68,3 +70,48 @@ def test_full_shape_windows_bit_exact(slb, oracle, N, M, steps):
         assert not sol.rows(5 + s.current, 0, 1).any()
     finally:
         sol.close()
+
+
+def _rows_to_compare(N, M):
+    """All rows of a lattice that fits comfortably, otherwise the rows around every place a
+    workgroup's chunk of rows may begin or end, the first and last rows, and every 16th."""
+    if (N + 1) * M <= 140 * (1 << 20):
+        return list(range(N + 1))
+    rows = set(range(4)) | set(range(N - 3, N + 1)) | set(range(0, N + 1, 16))
+    for chunk in ((7 * N + 15) // 16, N // 2, 32, 64):
+        for edge in range(chunk, N, chunk):
+            rows |= set(range(max(edge - 4, 0), min(edge + 4, N) + 1))
+    return sorted(rows)
+
+
+@pytest.mark.parametrize("N,M", [
+    (128, 1 << 20),          # config 3
+    (512, 1 << 20),          # config 5
+    (128, 1 << 23),          # config 4 on a single GPU
+    (256, 1 << 20),
+    (130, 300001),           # odd sizes: partial last chunk, ragged last strip
+])
+def test_full_shape_double_step_equals_the_two_sweep_form(slb, N, M):
+    """At full size the default form (two iterations per launch, rows per workgroup chosen by
+    the library) leaves the same bits in both current lattices as the two-sweep form, which
+    the test above holds to the oracle: four iterations each, row by row."""
+    import torch
+    kw = dict(N=N, M=M, E_dc=1.0, E_omega=0.1, omega=100.0, mu=5.0, alpha=1.0, B=4000.0 / M,
+              PhiYmin=-4.0, PhiYmax=4.0, dt=0.001)
+    slb.configure(**kw)
+    one, two = slb.Solver(), slb.Solver()
+    try:
+        one.tiptoe(); two.tiptoe()
+        for _ in range(4):
+            one.step()
+        two.double_step(); two.double_step()
+        torch.cuda.synchronize()
+        s1, s2 = one.s, two.s
+        assert (s1.current, s1.current_hs, s1.t) == (s2.current, s2.current_hs, s2.t)
+        for base, idx in ((1, s1.current), (5, s1.current), (1, s1.current_hs), (5, s1.current_hs)):
+            for r in _rows_to_compare(N, M):
+                x, y = one.rows(base + idx, r, 1), two.rows(base + idx, r, 1)
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (base, idx, r)
+    finally:
+        one.close()
+        two.close()
