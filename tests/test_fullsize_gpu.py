@@ -91,27 +91,33 @@ def _rows_to_compare(N, M):
     (256, 1 << 20),
     (130, 300001),           # odd sizes: partial last chunk, ragged last strip
 ])
-def test_full_shape_double_step_equals_the_two_sweep_form(slb, N, M):
+def test_full_shape_fused_forms_equal_the_two_sweep_form(slb, N, M):
     """At full size the default form (two iterations per launch, rows per workgroup chosen by
-    the library) leaves the same bits in both current lattices as the two-sweep form, which
-    the test above holds to the oracle: four iterations each, row by row."""
+    the library) and the one-launch-per-iteration form leave the same bits in both current
+    lattices as the two-sweep form, which the test above holds to the oracle: four iterations
+    each, row by row."""
     import torch
     kw = dict(N=N, M=M, E_dc=1.0, E_omega=0.1, omega=100.0, mu=5.0, alpha=1.0, B=4000.0 / M,
               PhiYmin=-4.0, PhiYmax=4.0, dt=0.001)
     slb.configure(**kw)
-    one, two = slb.Solver(), slb.Solver()
+    one, two, fus = slb.Solver(), slb.Solver(), slb.Solver()
     try:
-        one.tiptoe(); two.tiptoe()
+        one.tiptoe(); two.tiptoe(); fus.tiptoe()
         for _ in range(4):
             one.step()
+            fus.step_fused()                 # one launch per iteration
         two.double_step(); two.double_step()
         torch.cuda.synchronize()
-        s1, s2 = one.s, two.s
-        assert (s1.current, s1.current_hs, s1.t) == (s2.current, s2.current_hs, s2.t)
+        s1 = one.s
+        for other in (two, fus):
+            s2 = other.s
+            assert (s1.current, s1.current_hs, s1.t) == (s2.current, s2.current_hs, s2.t)
         for base, idx in ((1, s1.current), (5, s1.current), (1, s1.current_hs), (5, s1.current_hs)):
             for r in _rows_to_compare(N, M):
-                x, y = one.rows(base + idx, r, 1), two.rows(base + idx, r, 1)
-                assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (base, idx, r)
+                x = one.rows(base + idx, r, 1).view(np.uint32)
+                assert np.array_equal(x, two.rows(base + idx, r, 1).view(np.uint32)), ("double", base, idx, r)
+                assert np.array_equal(x, fus.rows(base + idx, r, 1).view(np.uint32)), ("fused", base, idx, r)
     finally:
         one.close()
         two.close()
+        fus.close()
