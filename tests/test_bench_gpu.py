@@ -1,0 +1,35 @@
+"""The bench contract: one JSON line with the agreed keys, for the three step forms."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("form", ["double", "fused", "sweeps"])
+def test_bench_prints_one_json_line(form):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                        "--form", form, "--no-cpu", "--g-grid-per-gpu", "65536"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["value"] > 0 and abs(d["ms_per_step"] * 1e-3 * d["value"] - 128 * 65536) < 1e-3 * 128 * 65536
+    assert "workload" in d["config"] and d["config"]["form"] == form
+    rf = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["traffic"] is None            # the counter figures on file are for the full-size lattice only
