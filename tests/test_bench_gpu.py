@@ -33,3 +33,25 @@ def test_bench_prints_one_json_line(form):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["traffic"] is None            # the counter figures on file are for the full-size lattice only
+
+
+def test_bench_over_two_slabs_prints_the_whole_job_rate():
+    """Two ranks sharing the GPU (halos staged over gloo, since RCCL refuses two ranks on one
+    device): rank 0 prints one line, `value` counts the columns of both slabs."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
+           "--warmup", "2", "--g-grid-per-gpu", "65536"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert "g-grid=131072" in d["config"]["workload"] and d["config"]["parallelism"] == "phi_y-slab x2"
+    assert abs(d["ms_per_step"] * 1e-3 * d["value"] - 128 * 131072) < 1e-3 * 128 * 131072
+    assert d["roofline"]["kernel"] == "fused2_step_kernel" and "note" in d["roofline"]
