@@ -3,7 +3,7 @@
 
 One "step" = one iteration of the time loop = main-lattice sweep + half-step
 lattice sweep over the whole (n-harmonics x g-grid) lattice.  The workload is
-BASELINE.json's roofline shape, n-harmonics=128 and g-grid=2^20 PER GPU: at
+the roofline shape, n-harmonics=128 and g-grid=2^20 PER GPU: at
 --gpus 1 that is config 3; at --gpus 8 the eight phi_y slabs make up config 4
 (g-grid=2^23), so the scaling reported is weak scaling.
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# BASELINE config 2 (display=77 trace, n-harmonics=64, g-grid=262144) by the single-GPU C program
+# The display=77 trace at n-harmonics=64, g-grid=262144 (the second named configuration) by the single-GPU C program
 # and by the slab program with 4 processes sharing the GPU (gloo): the traces must be identical.
 cd "$(dirname "$0")/.."
 ARGS="display=77 E_dc=1 E_omega=0.1 omega=100 mu=5 alpha=1 B=0.015 PhiYmin=-4 PhiYmax=4 dt=0.001 n-harmonics=64 g-grid=262144 t-max=0.05 quiet=1"

@@ -1,4 +1,4 @@
-"""Parity at BASELINE.json's full shapes.  The oracle cannot run whole lattices
+"""Parity at the full shapes of the named configurations.  The oracle cannot run whole lattices
 of this size in seconds, but it can run any WINDOW of columns (it takes a
 column offset), so each step of the GPU run is checked on windows at the left
 boundary, the centre and the right boundary, bit for bit; plus size-independent

@@ -221,7 +221,7 @@ def test_fused_step_bit_exact(slb, oracle, N, M, B, omega, steps, n_chunk):
 
 
 def test_program_config1_matches_recorded_reference_line(solver_bin, tmp_path):
-    """BASELINE config 1 end to end on the GPU (16 281 steps, av every step of the
+    """The reference's own CPU-runnable case end to end on the GPU (16 281 steps, av every step of the
     last period): the display=4 line equals, digit for digit, the line the
     compiled reference CPU solver printed when it was surveyed."""
     import json
