@@ -184,6 +184,14 @@ void slb_write_display4(float norm, const float *a01, const float *b1, int pitch
 void slb_write_display77(float norm, const float *a012, const float *b12, int pitch, float *av6, float t);
 void slb_close_output(void);
 
+/* the display=8 frame file written in pieces (reference: src/boltzmann_solver.c:487-507), for a
+ * caller that forms the frame values itself: the phi_x values of the file's blocks (returns
+ * their number), the head, one block from the values of columns 1..M+1, the closing norm */
+int   slb_frame_phi_x(float *phi, int max);
+void *slb_frame_begin(const char *name, float t);
+void  slb_frame_block(void *file, float phi_x, const float *vals);
+void  slb_frame_end(void *file, const float *a01, int pitch);
+
 /* the whole program behind main() */
 int slb_main(int argc, char **argv);
 

@@ -154,6 +154,50 @@ static int write_frame8(FILE *f, slb_solver *s, const float *a01, int pitch, flo
   return 0;
 }
 
+/* The same file written in pieces, for a caller that has the frame values itself (phi_y slabs:
+ * each slab forms the values of its columns, rank 0 puts the rows together):
+ * slb_frame_phi_x() lists the phi_x values of the file's blocks, slb_frame_begin() opens
+ * the file and writes its head, slb_frame_block() one phi_x block from the M+1 values of
+ * columns 1..M+1, slb_frame_end() the closing norm (a01 = rows 0 and 1 of a). */
+int slb_frame_phi_x(float *phi, int max)
+{
+  int n = 0;
+  for (float phi_x = -SLB_PI; phi_x < SLB_PI; phi_x += 0.01) {
+    if (n < max) phi[n] = phi_x;
+    n++;
+  }
+  return n;
+}
+
+void *slb_frame_begin(const char *name, float t)
+{
+  FILE *f = fopen(name, "w");
+  if (!f) { perror("ERROR"); return NULL; }
+  printf("\nWriting frame %s\n", name);
+  fprintf(f, "# t=%0.20f\n", t);
+  return f;
+}
+
+void slb_frame_block(void *file, float phi_x, const float *vals)
+{
+  line_frame((FILE *)file, NULL, phi_x, 0, vals, NULL, host_M + 1);
+}
+
+void slb_frame_end(void *file, const float *a01, int pitch)
+{
+  FILE *f = (FILE *)file;
+  const int cpu_pitch = host_M + 3;
+  float norm = 0;
+  for (int m = 1; m < 2 * host_M + 2; m++) {
+    const int r = m >= cpu_pitch ? 1 : 0;
+    norm += a01[(size_t)r * pitch + (m - r * cpu_pitch)] * host_dPhi;
+  }
+  norm *= 2 * SLB_PI * sqrt(host_alpha);
+  fprintf(f, "# norm=%0.20f\n", norm);
+  printf("# norm=%0.20f\n", norm);
+  fclose(f);
+}
+
 /* display=9 strobe file: this period's frame added to the running image
  * (reference: src/boltzmann_solver.c:459-484) */
 static int write_strobe(FILE *f, slb_solver *s, float *strobe, const float *a0row, float t)

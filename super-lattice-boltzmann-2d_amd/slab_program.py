@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""display=4 and display=77 runs of the boltzmann_solver program over phi_y slabs, one process per GPU.
+"""display=4, display=8 and display=77 runs of the boltzmann_solver program over phi_y slabs, one
+process per GPU.
 
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 \\
         super-lattice-boltzmann-2d_amd/slab_program.py display=4 E_dc=1 ... g-grid=8388608 o=out.txt
@@ -53,9 +54,10 @@ def main(argv):
     L.parse_cmd.argtypes, L.parse_cmd.restype = [C.c_int, C.POINTER(C.c_char_p)], None
     L.parse_cmd(len(args) + 1, cargs)
     display = C.c_int.in_dll(L, "display").value
-    if display not in (4, 77):
+    if display not in (4, 8, 77):
         if rank == 0:
-            sys.stderr.write("ERROR: the slab program writes display=4 records and display=77 traces only.\n")
+            sys.stderr.write("ERROR: the slab program writes display=4 records, display=8 frames and "
+                             "display=77 traces only.\n")
         return 1
     L.slb_derive_and_load()
     g = slb.get_global
@@ -88,7 +90,7 @@ def main(argv):
         """What follows the step taken at loop time t: 0 nothing, 1 av(), 2 a display=77 record."""
         if display == 77:
             return 2 if E_omega > 0 and np.float64(ft) >= 0.01 else 0
-        return 1 if averaged(t) else 0
+        return 1 if display == 4 and averaged(t) else 0
 
     fp = C.c_void_p
     L.slb_host_norm.argtypes, L.slb_host_norm.restype = [fp, C.c_int, C.c_float, C.c_float], C.c_float
@@ -191,6 +193,37 @@ def main(argv):
             L.slb_write_display4.restype = None
             norm = L.slb_host_norm(a_rows.ctypes.data, M, g("host_dPhi"), g("host_alpha"))
             L.slb_write_display4(norm, a_rows.ctypes.data, b_row.ctypes.data, M + 3, av6.ctypes.data, float(T))
+    # display=8: f(phi_x, phi_y) of the final lattice; every slab forms the values of its own
+    # columns on its GPU, rank 0 writes the file a batch of phi_x values at a time
+    if display == 8:
+        s = sol.s
+        phis = np.empty(1024, dtype=np.float32)
+        L.slb_frame_phi_x.argtypes, L.slb_frame_phi_x.restype = [fp, C.c_int], C.c_int
+        nphi = L.slb_frame_phi_x(phis.ctypes.data, len(phis))
+        phis = phis[:nphi]
+        a01, _ = gather_rows(1 + s.current, 5 + s.current, 2, 1, 1)
+        f = None
+        if rank == 0:
+            L.slb_frame_begin.argtypes, L.slb_frame_begin.restype = [C.c_char_p, C.c_float], fp
+            L.slb_frame_block.argtypes, L.slb_frame_block.restype = [fp, C.c_float, fp], None
+            L.slb_frame_end.argtypes, L.slb_frame_end.restype = [fp, fp, C.c_int], None
+            f = L.slb_frame_begin(b"frame.data", float(t))
+            if not f:
+                raise RuntimeError("cannot open frame.data")
+        batch = max(8, min(640, (16 << 20) // (M + 1)))
+        for p0 in range(0, nphi, batch):
+            part = sol.frame_values(phis[p0:p0 + batch])
+            parts = [part]
+            if world > 1:
+                parts = [None] * world if rank == 0 else None
+                dist.gather_object(part, parts, dst=0)
+            if rank == 0:
+                vals = np.ascontiguousarray(np.concatenate(parts, axis=1))
+                assert vals.shape[1] == M + 1
+                for k in range(vals.shape[0]):
+                    L.slb_frame_block(f, float(phis[p0 + k]), vals[k].ctypes.data)
+        if rank == 0:
+            L.slb_frame_end(f, a01.ctypes.data, M + 3)
     if rank == 0:
         L.slb_close_output.argtypes, L.slb_close_output.restype = [], None
         L.slb_close_output()

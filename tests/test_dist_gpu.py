@@ -186,6 +186,28 @@ def test_slab_program_display77_trace(world, tmp_path, solver_bin):
     assert pick(one.stdout) == pick(many.stdout)
 
 
+@pytest.mark.parametrize("world,grid", [(1, "61"), (3, "61"), (3, "2500")])
+def test_slab_program_display8_frame(world, grid, tmp_path, solver_bin):
+    """display=8 over slabs: every slab forms the frame values of its columns, rank 0 writes
+    frame.data; the file equals the single-GPU program's byte for byte."""
+    import subprocess
+    args = ["display=8", "E_dc=1", "E_omega=0.1", "omega=100", "mu=5", "alpha=1", "B=0.5", "PhiYmin=-4",
+            "PhiYmax=4", "dt=0.001", "n-harmonics=8", "g-grid=" + grid, "t-max=0.01", "quiet=1", "o=out.txt"]
+    (tmp_path / "one").mkdir(), (tmp_path / "many").mkdir()
+    one = subprocess.run([solver_bin] + args, cwd=tmp_path / "one", capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stdout + one.stderr
+    script = os.path.join(sh.ROOT, sh.PKG, "slab_program.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(sh.free_port()), script] + args
+    many = subprocess.run(cmd, cwd=tmp_path / "many", capture_output=True, text=True, timeout=300,
+                          env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
+    assert many.returncode == 0, many.stdout + many.stderr
+    a, b = (tmp_path / "one" / "frame.data").read_bytes(), (tmp_path / "many" / "frame.data").read_bytes()
+    assert len(a.splitlines()) == 629 * (int(grid) + 1) + 2
+    assert a == b
+    assert [l for l in one.stdout.splitlines() if "norm" in l] == [l for l in many.stdout.splitlines() if "norm" in l]
+
+
 @pytest.mark.parametrize("world", [1, 3])
 def test_slab_program_with_tree_sums(world, tmp_path, solver_bin):
     """The same with SLB_AV=tree (per-slab sums in double, all-reduced): the instantaneous
