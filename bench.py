@@ -7,15 +7,24 @@ the roofline shape, n-harmonics=128 and g-grid=2^20 PER GPU: at
 --gpus 1 that is config 3; at --gpus 8 the eight phi_y slabs make up config 4
 (g-grid=2^23), so the scaling reported is weak scaling.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
 
+With N > 1 and no WORLD_SIZE in the environment this process only starts the N
+ranks (python -m torch.distributed.run ... bench.py, one per GPU) before it has
+touched a GPU, passes their output through and exits with their status; started
+by torch.distributed.run itself it is one of the ranks.
+
+The timed block of exactly K steps (barrier + device synchronisation on both
+sides, maximum over ranks) is repeated --repeats times; `value` and
+`ms_per_step` are those of the median block, the spread is reported beside them.
 Prints one JSON line (rank 0).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,13 +38,37 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
 BYTES_PER_POINT_SWEEP = 28     # two-sweep form: 5 fp32 reads + 2 fp32 writes per point per sweep
 BYTES_PER_UPDATE_FUSED = 36    # one-launch step: 5 reads + 4 writes per lattice-point-update
 BYTES_PER_UPDATE_DOUBLE = 18   # two steps per launch: the same 9 accesses serve two updates
+TRAFFIC_FILE = os.path.join("profiles", "hbm_traffic.json")
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_threads():
+    """Threads for the CPU baseline: OMP_NUM_THREADS where the machine sets it (a GPU box gives
+    a job its share of the host's cores that way), else every CPU this process may run on."""
+    env = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    if env > 0:
+        return env, "OMP_NUM_THREADS"
+    try:
+        return len(os.sched_getaffinity(0)), "sched_getaffinity"
+    except AttributeError:
+        return os.cpu_count() or 1, "cpu_count"
 
 
 def cpu_baseline(n_harm, g_grid, phys, steps):
     """The CPU oracle (a restatement of the reference's OpenMP solver) on the
     host cores, same lattice shape, a few steps."""
     import oracle_binding as ob
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    threads, source = cpu_threads()
     p = ob.make_params(N=n_harm, M=g_grid, **phys)
     st = ob.OracleState(p, threads=threads)
     st.step(1)                                   # touch every page once
@@ -43,8 +76,13 @@ def cpu_baseline(n_harm, g_grid, phys, steps):
     st.step(steps)
     dt = time.perf_counter() - t0
     st.close()
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = None
     return {"value": n_harm * g_grid * steps / dt, "unit": "lattice-point-updates/s",
-            "cores": threads, "kind": "port",
+            "cores": threads, "threads_from": source, "nproc": os.cpu_count(), "affinity": affinity,
+            "cpu_model": cpu_model(), "kind": "port", "seconds": dt,
             "sample": f"{steps} steps of the same n-harmonics={n_harm} g-grid={g_grid} lattice "
                       f"(OpenMP over phi_y, {threads} threads), after 1 untimed step"}
 
@@ -79,11 +117,13 @@ def config1_case(slb, torch):
             "gpu_steps": steps, "cpu_steps": cpu_steps}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed blocks of --steps steps each; the median block is reported")
     ap.add_argument("--n-harmonics", type=int, default=N_HARMONICS)
     ap.add_argument("--g-grid-per-gpu", type=int, default=G_GRID_PER_GPU)
     ap.add_argument("--variant", type=int, default=0)
@@ -93,9 +133,102 @@ def main():
                     help="double: two steps (four sweeps) per launch (default); "
                          "fused: both sweeps of a step in one launch; "
                          "sweeps: the reference's two launches per step")
+    ap.add_argument("--driver", choices=("auto", "c", "torch"), default="auto",
+                    help="N > 1: who orders the slab launches and moves the halo columns. c: the C slab "
+                         "driver calling RCCL itself (host/slb_slabs.c); torch: torch.distributed "
+                         "point-to-point operations (dist.py); auto: c over RCCL, torch for gloo rehearsals")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-two-sweep", action="store_true", help="skip the two-sweep leg of the default run")
+    ap.add_argument("--two-sweep-steps", type=int, default=10)
     ap.add_argument("--cpu-steps", type=int, default=20)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """--gpus N without a rank environment: start the N ranks as children.  Nothing here has
+    touched a GPU (torch is not even imported), so the children are the only GPU processes."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
+def alg_bytes_per_launch(form, n_harm, cols):
+    """Algorithmic bytes of the dominant kernel's launch on `cols` grid columns: the main sweep
+    covers cols+1 columns and the half-step sweep cols, hence the half column."""
+    points = n_harm * (cols + 0.5)
+    if form == "double":       # one launch = two steps, the same 9 array passes
+        return "fused2_step_kernel", 2 * BYTES_PER_UPDATE_DOUBLE * points
+    if form == "fused":
+        return "fused_step_kernel", BYTES_PER_UPDATE_FUSED * points
+    return "sweep_pipe_kernel", BYTES_PER_POINT_SWEEP * points
+
+
+def recorded_traffic(form, n_harm, g_grid):
+    """HBM bytes per launch counted by rocprofv3 --pmc for this form and lattice in an earlier
+    run of this command (profiles/hbm_traffic.json), or None: counters cannot be read from
+    inside the timed process."""
+    tfile = os.path.join(ROOT, TRAFFIC_FILE)
+    if not os.path.exists(tfile):
+        return None, None
+    with open(tfile) as f:
+        tj = json.load(f)
+    for key, e in tj.items():
+        if isinstance(e, dict) and e.get("form", key) == form and e.get("n_harmonics") == n_harm \
+                and e.get("g_grid") == g_grid:
+            return e.get("bytes_per_launch"), f"{TRAFFIC_FILE}:{key} ({e.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')})"
+    return None, None
+
+
+def roofline(form, n_harm, cols, kernel_ms, traffic=None, traffic_source=None):
+    kernel, alg = alg_bytes_per_launch(form, n_harm, cols)
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": kernel, "avg_launch_ms": kernel_ms, "algorithmic_bytes_per_launch": alg}
+
+
+def launches_per(form, steps):
+    return {"double": steps // 2 + steps % 2, "fused": steps, "sweeps": 2 * steps}[form]
+
+
+def median_block(blocks):
+    """blocks: list of (wall seconds, kernel ms or None).  The block with the median wall time."""
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
+    return blocks[order[(len(blocks) - 1) // 2]]
+
+
+def run_single(args, slb, torch, form, steps, warmup, repeats):
+    sol = slb.Solver(0, 1)
+    sol.tiptoe()
+    sol.set_fused({"double": 2, "fused": 1, "sweeps": 0}[form])
+    warm = warmup
+    if form == "double":
+        # an even number of warm-up steps keeps the ping-pong parity the spare arrays were
+        # made for (an odd count would re-copy them inside the timed region)
+        warm += warm % 2
+        sol.double_step()                    # allocates the spare arrays outside the timed region
+    sol.run_timed(warm)
+    blocks = []
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev_ms = sol.run_timed(steps)             # HIP events on the launch stream
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        blocks.append((wall, ev_ms / launches_per(form, steps)))   # launches are back to back
+    sol.close()
+    return blocks
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     import torch
     slb = importlib.import_module("super-lattice-boltzmann-2d_amd")
@@ -104,18 +237,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     torch.zeros(1, device="cuda")              # make this device current for the C library too
     # SLB_DIST_BACKEND=gloo: rehearsal of the multi-rank path where RCCL cannot run (several
     # ranks on one GPU); halo messages are then staged through host memory
     backend = os.environ.get("SLB_DIST_BACKEND", "nccl")
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
         else:
             dist.init_process_group(backend)
+        ranks_seen = dist.get_world_size()
 
     n_harm = args.n_harmonics
     g_grid = args.g_grid_per_gpu * world
@@ -130,33 +265,24 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream())
     L.slb_set_stream(torch.cuda.current_stream().cuda_stream)
     L.slb_set_tuning(args.variant, args.n_chunk, args.block)
+    repeats = max(args.repeats, 1)
 
-    kernel_ms = None
+    driver = None
     if world == 1:
-        sol = slb.Solver(0, 1)
-        sol.tiptoe()
-        sol.set_fused({"double": 2, "fused": 1, "sweeps": 0}[args.form])
-        warm = args.warmup
-        if args.form == "double":
-            # an even number of warm-up steps keeps the ping-pong parity the spare arrays were
-            # made for (an odd count would re-copy them inside the timed region)
-            warm += warm % 2
-            sol.double_step()                    # allocates the spare arrays outside the timed region
-        sol.run_timed(warm)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ev_ms = sol.run_timed(args.steps)        # HIP events on the launch stream
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        n_launches = {"double": args.steps // 2 + args.steps % 2, "fused": args.steps,
-                      "sweeps": 2 * args.steps}[args.form]
-        kernel_ms = ev_ms / n_launches           # launches are back to back
-        sol.close()
+        blocks = run_single(args, slb, torch, args.form, args.steps, args.warmup, repeats)
     else:
         import torch.distributed as dist
         drv = importlib.import_module("super-lattice-boltzmann-2d_amd.dist")
-        run = drv.SlabRun(slb, rank, world)
+        driver = args.driver
+        if driver == "auto":
+            driver = "c" if (backend == "nccl" and hasattr(drv, "CSlabRun")) else "torch"
+        if driver == "c":
+            run = drv.CSlabRun(slb, rank, world, backend)
+            ranks_seen = run.ranks_seen()
+        else:
+            run = drv.SlabRun(slb, rank, world)
         run.tiptoe()
+
         def advance(nsteps):
             k = 0
             if args.form == "double":
@@ -167,34 +293,43 @@ def main():
                 (run.step if args.form == "sweeps" else run.step_fused)()
 
         advance(max(args.warmup + args.warmup % 2, 2))
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()                                 # on the stream of the interior launches
-        advance(args.steps)
-        ev1.record()
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        if args.form == "double" and args.steps % 2 == 0:
-            # this rank's stream time per double step: the interior launch (the edge launches
-            # and the halo traffic run beside it) plus whatever it had to wait for
-            kernel_ms = ev0.elapsed_time(ev1) / (args.steps // 2)
-        w = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        wall = float(w.item())
+        blocks = []
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record()                                 # on the stream of the interior launches
+            advance(args.steps)
+            ev1.record()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            kernel_ms = None
+            if args.form == "double" and args.steps % 2 == 0:
+                # this rank's stream time per double step: the interior launch (the edge launches
+                # and the halo traffic run beside it) plus whatever it had to wait for
+                kernel_ms = ev0.elapsed_time(ev1) / (args.steps // 2)
+            w = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            blocks.append((float(w.item()), kernel_ms))
         run.close()
 
+    wall, kernel_ms = median_block(blocks)
+    walls = [b[0] for b in blocks]
     updates = float(n_harm) * float(g_grid) * args.steps
     value = updates / wall
+    bytes_per_update = {"double": BYTES_PER_UPDATE_DOUBLE, "fused": BYTES_PER_UPDATE_FUSED,
+                        "sweeps": 2 * BYTES_PER_POINT_SWEEP}[args.form]
     out = {
         "metric": "lattice-point-updates/sec (n-harmonics x g-grid per step)",
         "value": value, "unit": "lattice-point-updates/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3,
+        "repeats": repeats,
+        "ms_per_step_min": min(walls) / args.steps * 1e3, "ms_per_step_max": max(walls) / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (analytic equilibrium initial state, no RNG)",
         "config": {"workload": f"n-harmonics={n_harm} g-grid={g_grid} "
@@ -202,38 +337,34 @@ def main():
                                f"omega=100 B={phys['B']:.6g} dt=0.001, 2 sweeps per step",
                    "form": args.form, "parallelism": f"phi_y-slab x{world}"},
         # whole-job rate against the per-GPU HBM peak, with the bytes this form must move ...
-        "hbm_roofline_frac_per_gpu": {"double": BYTES_PER_UPDATE_DOUBLE, "fused": BYTES_PER_UPDATE_FUSED,
-                                      "sweeps": 2 * BYTES_PER_POINT_SWEEP}[args.form]
-                                     * value / world / (HBM_PEAK_GBS * 1e9),
+        "hbm_roofline_frac_per_gpu": bytes_per_update * value / world / (HBM_PEAK_GBS * 1e9),
         # ... and with the 56 B/update of the reference's two-sweep formulation, for comparison
         "equiv_two_sweep_traffic_frac_per_gpu": 2 * BYTES_PER_POINT_SWEEP * value / world / (HBM_PEAK_GBS * 1e9),
     }
+    if driver is not None:
+        out["config"]["driver"] = {"c": "C slab driver, RCCL send/recv called from C",
+                                   "torch": "torch.distributed point-to-point operations"}[driver]
+        out["config"]["backend"] = backend
     if rank == 0:
         if kernel_ms is not None:
-            # dominant kernel; one launch = one step (fused) or one sweep of the whole lattice
-            points = n_harm * (g_grid / world + 0.5)      # main sweep M+1 columns, half sweep M; per GPU
-            if args.form == "double":      # one launch = two steps, the same 9 array passes
-                kernel, alg_bytes = "fused2_step_kernel", 2 * BYTES_PER_UPDATE_DOUBLE * points
-            elif args.form == "fused":
-                kernel, alg_bytes = "fused_step_kernel", BYTES_PER_UPDATE_FUSED * points
-            else:
-                kernel, alg_bytes = "sweep_pipe_kernel", BYTES_PER_POINT_SWEEP * points
-            achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(tfile):
-                with open(tfile) as f:
-                    tj = json.load(f)
-                tj = tj.get(args.form, {})
-                if world == 1 and tj.get("n_harmonics") == n_harm and tj.get("g_grid") == g_grid:
-                    traffic = tj.get("bytes_per_launch")
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": kernel, "avg_launch_ms": kernel_ms,
-                               "algorithmic_bytes_per_launch": alg_bytes}
+            traffic, source = (None, None)
+            if world == 1:
+                traffic, source = recorded_traffic(args.form, n_harm, g_grid)
+            out["roofline"] = roofline(args.form, n_harm, g_grid / world, kernel_ms, traffic, source)
             if world > 1:
                 out["roofline"]["note"] = ("rank 0's slab; stream time per double step including waits "
                                            "for halo columns, not the bare kernel")
+        if world == 1 and args.form != "sweeps" and not args.no_two_sweep:
+            # the reference's own formulation (two launches per step, 28 B per point per sweep),
+            # timed in the same process
+            b2 = run_single(args, slb, torch, "sweeps", args.two_sweep_steps, 2, 3)
+            w2, k2 = median_block(b2)
+            t2, s2 = recorded_traffic("sweeps", n_harm, g_grid)
+            two = roofline("sweeps", n_harm, g_grid, k2, t2, s2)
+            two.update({"steps": args.two_sweep_steps, "repeats": 3,
+                        "value": n_harm * g_grid * args.two_sweep_steps / w2,
+                        "ms_per_step": w2 / args.two_sweep_steps * 1e3})
+            out["two_sweep"] = two
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(n_harm, g_grid, phys, args.cpu_steps)
             out["config1"] = config1_case(slb, torch)

@@ -45,6 +45,15 @@ class StepGeom(C.Structure):
                 ("j2_first", C.c_int), ("j2_last", C.c_int)]
 
 
+class Step2Geom(C.Structure):
+    _fields_ = [("pitch", C.c_int), ("m_offset", C.c_int), ("j_first", C.c_int * 4), ("j_last", C.c_int * 4)]
+
+
+class MultiGeom(C.Structure):
+    _fields_ = [("pitch", C.c_int), ("m_offset", C.c_int), ("steps", C.c_int),
+                ("j_first", C.c_int * 8), ("j_last", C.c_int * 8)]
+
+
 class HaloSeg(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("col", C.c_int), ("ncols", C.c_int),
                 ("buf", C.c_void_p)]
@@ -87,6 +96,14 @@ def lib():
         L.slb_sweep.restype = i
         L.slb_step_fused.argtypes = [C.POINTER(StepGeom)] + [fp] * 9 + [C.POINTER(C.c_float * 4)]
         L.slb_step_fused.restype = i
+        L.HandleError.argtypes, L.HandleError.restype = [i, C.c_char_p, i], None
+        L.slb_step_fused2.argtypes = [C.POINTER(Step2Geom)] + [fp] * 13 + [C.POINTER(C.c_float * 8)]
+        L.slb_step_fused2.restype = i
+        L.slb_step_fused2_rows.argtypes = [C.POINTER(Step2Geom)] + [fp] * 13 + [C.POINTER(C.c_float * 8), fp, fp]
+        L.slb_step_fused2_rows.restype = i
+        L.slb_step_multi.argtypes = [C.POINTER(MultiGeom), fp, C.POINTER(C.c_void_p * 4), C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p * 4), C.POINTER(C.c_float)]
+        L.slb_step_multi.restype = i
         L.slb_halo_pack.argtypes = [fp, fp, i, i, i, i, fp]
         L.slb_halo_pack.restype = i
         L.slb_halo_unpack.argtypes = [fp, fp, i, i, i, i, fp]
@@ -129,6 +146,7 @@ def lib():
         pp = C.POINTER(C.c_void_p)
         L.slb_av_sums_exact_from_n.argtypes = [C.POINTER(Slab), i, pp, pp, pp, pp]
         L.slb_av_sums_exact_from_n.restype = i
+        L.slb_av_sums_exact_n.argtypes, L.slb_av_sums_exact_n.restype = [C.POINTER(Slab), i, pp, pp, pp], i
         L.slb_solver_copy_av_rows.argtypes, L.slb_solver_copy_av_rows.restype = [C.POINTER(SolverStruct), fp], i
         L.slb_solver_double_step_range.argtypes = [C.POINTER(SolverStruct), i, i, C.POINTER(C.c_float * 8)]
         L.slb_solver_double_step_range.restype = None

@@ -40,6 +40,7 @@ int         g_variant = 0, g_n_chunk = 0, g_block = 0;
 double     *g_ws = nullptr;          // reduction workspace, allocated once
 int         g_ws_device = -1;
 constexpr int kMaxAvBlocks = 1024;
+constexpr int kAvColsPerBlock = 256 * 8;   // columns a block of the tree sums takes per pass
 
 struct SweepArgs {
   const float *a0, *a_c, *b_c, *a_s, *b_s;
@@ -1225,8 +1226,10 @@ __global__ void __launch_bounds__(64) av_exact_kernel(const AvSets sets)
     term[t] = j <= p.j_last ? av_term(p, q, j) : 0.0f;
   }
   while (base <= p.j_last) {
+    __syncthreads();                                 // lane 0 has finished with the last group
 #pragma unroll
     for (int t = 0; t < T; t++) park[t * 64 + lane] = term[t];
+    __syncthreads();                                 // all 64 lanes' terms are in place
     const int nb = base + B;
 #pragma unroll
     for (int t = 0; t < T; t++) {                    // next group's loads fly during the chain
@@ -1381,12 +1384,12 @@ __device__ float seq_sum_block(F term, int n, ScanShared<W, T> &sh, int *stats =
       const int t_bad = badmask ? __builtin_ctz(badmask) : T;
       const unsigned long long vote = __ballot(badmask != 0);
       const int first = vote ? (int)__ffsll((long long)vote) - 1 : 64;
-      if (lane == 0) sh.first_bad[w] = 0x7fffffff;
-      if (lane == first) {
+      // one lane per wave reports: the first lane with a bad term, or lane 0 that there is none
+      if (lane == (vote ? first : 0)) {
         int prev = before;                                  // the sum before my first bad term
 #pragma unroll
         for (int t = 1; t < T; t++) prev = t == t_bad ? before + ps[t - 1] : prev;
-        sh.first_bad[w] = e0 + t_bad;
+        sh.first_bad[w] = vote ? e0 + t_bad : 0x7fffffff;
         sh.prev_sum[w]  = prev;
       }
       if (e0 <= count - 1 && count - 1 < e0 + T) {
@@ -1519,14 +1522,22 @@ __global__ void __launch_bounds__(256) frame_kernel(const float *__restrict__ a,
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+constexpr int kMaxDevices = 64;
+constexpr size_t kWsDoubles = kMaxAvBlocks * 3 + 4;      // block partials, then 4 doubles for totals
+double *g_ws_of[kMaxDevices] = {};                       // one workspace per device, kept until exit
+
+// the reduction workspace of the current device (allocated on first use there) -> g_ws
 int ensure_workspace()
 {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
-  if (g_ws && g_ws_device == dev) return 0;
-  e = hipMalloc((void **)&g_ws, sizeof(double) * (kMaxAvBlocks * 3 + 4));
-  if (e != hipSuccess) { g_ws = nullptr; return (int)e; }
+  if (dev < 0 || dev >= kMaxDevices) { fprintf(stderr, "libslb2d: device index %d not supported\n", dev); return -1; }
+  if (!g_ws_of[dev]) {
+    e = hipMalloc((void **)&g_ws_of[dev], sizeof(double) * kWsDoubles);
+    if (e != hipSuccess) { g_ws_of[dev] = nullptr; return (int)e; }
+  }
+  g_ws = g_ws_of[dev];
   g_ws_device = dev;
   return 0;
 }
@@ -2025,18 +2036,24 @@ static AvArgs make_av_args(const slb_slab *slab, const float *a, const float *b)
   return p;
 }
 
+// tree sums of a slab with the block partials in ws (kMaxAvBlocks * 3 doubles)
+static int av_partial_ws(const slb_slab *slab, const float *a, const float *b, double *ws, double *sums)
+{
+  const AvArgs p = make_av_args(slab, a, b);
+  const int cols = slab->j_last - slab->j_first + 1;
+  int nb = cols > 0 ? (cols + kAvColsPerBlock - 1) / kAvColsPerBlock : 1;
+  if (nb > kMaxAvBlocks) nb = kMaxAvBlocks;
+  hipLaunchKernelGGL(av_partial_kernel, dim3(nb), dim3(256), 0, g_stream, p, ws);
+  hipLaunchKernelGGL(av_combine_kernel, dim3(1), dim3(64), 0, g_stream, (const double *)ws, nb, sums);
+  return (int)hipGetLastError();
+}
+
 int slb_av_partial(const slb_slab *slab, const float *a, const float *b, double *sums)
 {
   if (!g_phys.loaded || !slab || slab->j_first < 0 || slab->j_last >= slab->pitch) return -1;
   int rc = ensure_workspace();
   if (rc) return rc;
-  const AvArgs p = make_av_args(slab, a, b);
-  const int cols = slab->j_last - slab->j_first + 1;
-  int nb = cols > 0 ? (cols + 256 * 8 - 1) / (256 * 8) : 1;
-  if (nb > kMaxAvBlocks) nb = kMaxAvBlocks;
-  hipLaunchKernelGGL(av_partial_kernel, dim3(nb), dim3(256), 0, g_stream, p, g_ws);
-  hipLaunchKernelGGL(av_combine_kernel, dim3(1), dim3(64), 0, g_stream, (const double *)g_ws, nb, sums);
-  return (int)hipGetLastError();
+  return av_partial_ws(slab, a, b, g_ws, sums);
 }
 
 int slb_av_update(const double *sums, float *av_data, float t)
@@ -2090,24 +2107,29 @@ int slb_av_update_exact(const float *tot3, float *av_data, float t)
   return (int)hipGetLastError();
 }
 
-void av(int blocks, float *a, float *b, float *av_data, float t)
+// av() with its workspace given: ws[0 .. 3*kMaxAvBlocks) block partials (tree sums),
+// then 4 doubles for the totals handed from the sums to the update
+static int av_with_workspace(double *ws, const float *a, const float *b, float *av_data, float t)
 {
-  (void)blocks;
   // columns 1..M, i.e. m < TMSIZE (reference: src/boltzmann_c_solver.c:417)
   const slb_slab slab = {g_phys.pitch, 0, 1, g_phys.TMSIZE - 1};
   int rc;
   if (g_av_mode == SLB_AV_TREE) {
-    rc = ensure_workspace();
-    if (rc == 0) rc = slb_av_partial(&slab, a, b, g_ws + kMaxAvBlocks * 3);
-    if (rc == 0) rc = slb_av_update(g_ws + kMaxAvBlocks * 3, av_data, t);
+    rc = av_partial_ws(&slab, a, b, ws, ws + kMaxAvBlocks * 3);
+    if (rc == 0) rc = slb_av_update(ws + kMaxAvBlocks * 3, av_data, t);
   } else {
-    rc = ensure_workspace();
-    if (rc == 0) {
-      float *tot = reinterpret_cast<float *>(g_ws + kMaxAvBlocks * 3);   // 4 doubles kept for totals
-      rc = slb_av_sums_exact(&slab, a, b, tot);
-      if (rc == 0) rc = slb_av_update_exact(tot, av_data, t);
-    }
+    float *tot = reinterpret_cast<float *>(ws + kMaxAvBlocks * 3);
+    rc = slb_av_sums_exact(&slab, a, b, tot);
+    if (rc == 0) rc = slb_av_update_exact(tot, av_data, t);
   }
+  return rc;
+}
+
+void av(int blocks, float *a, float *b, float *av_data, float t)
+{
+  (void)blocks;
+  int rc = g_phys.loaded ? ensure_workspace() : -1;
+  if (rc == 0) rc = av_with_workspace(g_ws, a, b, av_data, t);
   if (rc > 0) HandleError(rc, __FILE__, __LINE__);
   if (rc < 0) exit(EXIT_FAILURE);
 }

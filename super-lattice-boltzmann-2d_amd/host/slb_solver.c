@@ -590,8 +590,8 @@ int slb_solver_frame_values(slb_solver *s, int source, const float *phi_x, int n
 
 int slb_solver_get_rows(slb_solver *s, int arr, int row0, int nrows, float *dst)
 {
-  const float *src = arr == 0 ? s->a0 : (arr <= 4 ? s->a[arr - 1] : s->b[arr - 5]);
   if (arr < 0 || arr > 8 || row0 < 0 || nrows < 1 || row0 + nrows > s->N + 1) return -1;
+  const float *src = arr == 0 ? s->a0 : (arr <= 4 ? s->a[arr - 1] : s->b[arr - 5]);
   HIP_OK(hipMemcpy(dst, src + (size_t)row0 * s->pitch, (size_t)nrows * s->pitch * sizeof(float),
                    hipMemcpyDeviceToHost));
   return 0;

@@ -28,6 +28,34 @@ def test_library_exports_every_declared_symbol(slb):
         C.c_int.in_dll(L, name)
 
 
+def test_every_bound_function_declares_its_argument_types(slb):
+    """A call through ctypes without argtypes passes Python ints as C ints: a 64-bit device
+    pointer would be cut to 32 bits without a word.  Every function of the header has them."""
+    L = slb.lib()
+    for name in slb.ABI_FUNCTIONS:
+        fn = getattr(L, name)
+        assert fn.argtypes is not None, name
+    assert L.slb_version().startswith(b"slb2d")
+
+
+def test_half_step_sweep_leaves_the_last_main_column_alone(oracle):
+    """The parity target's half-step sweep stops at column M (reference:
+    src/boltzmann_c_solver.c:391, `m < TMSIZE`), one column before the reference's CUDA
+    kernels do (src/boltzmann_gpu.cu:176): column M+1 of the output arrays keeps what it held."""
+    import numpy as np
+    N, M = 6, 40
+    p = oracle.make_params(N=N, M=M)
+    rng = np.random.default_rng(5)
+    arr = lambda: rng.standard_normal((N + 1, M + 3)).astype(np.float32)
+    a0, ac, bc, a_s, b_s = arr(), arr(), arr(), arr(), arr()
+    a_out, b_out = np.full((N + 1, M + 3), 7.0, np.float32), np.full((N + 1, M + 3), 9.0, np.float32)
+    oracle.lib().orc_step_on_half_grid(C.byref(p), a0, a_s, b_s, ac, bc, a_out, b_out, 0.5, 0.25)
+    assert np.all(a_out[:, M + 1:] == 7.0) and np.all(b_out[:, M + 1:] == 9.0) and np.all(a_out[:, 0] == 7.0)
+    assert np.all(a_out[:N, 1:M + 1] != 7.0) and np.all(a_out[N] == 7.0) and np.all(b_out[0] == 9.0)
+    oracle.lib().orc_step_on_grid(C.byref(p), a0, ac, bc, a_out, b_out, a_s, b_s, 0.5, 0.25)
+    assert np.all(a_out[:N, M + 1] != 7.0) and np.all(a_out[:, M + 2] == 7.0)
+
+
 def test_derived_constants_follow_the_reference_formulas(slb):
     d = slb.configure(N=32, M=4096, E_dc=1.0, E_omega=0.1, omega=1.0, mu=5.0, alpha=1.0, B=1.0,
                       PhiYmin=-4.0, PhiYmax=4.0, dt=0.001)

@@ -32,7 +32,15 @@ def test_bench_prints_one_json_line(form):
         assert key in rf, key
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert rf["traffic"] is None            # the counter figures on file are for the full-size lattice only
+    assert rf["traffic"] is None and rf["traffic_source"] is None   # counter figures on file are for full-size lattices
+    assert d["repeats"] == 5 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    assert d["ranks_seen"] == 1
+    if form == "sweeps":
+        assert "two_sweep" not in d
+    else:
+        two = d["two_sweep"]                # the reference's formulation, timed in the same process
+        assert two["kernel"] == "sweep_pipe_kernel" and two["steps"] == 10 and two["frac"] > 0
+        assert abs(two["frac"] - two["achieved"] / two["peak"]) < 1e-12
 
 
 def test_bench_over_two_slabs_prints_the_whole_job_rate():
@@ -55,3 +63,25 @@ def test_bench_over_two_slabs_prints_the_whole_job_rate():
     assert "g-grid=131072" in d["config"]["workload"] and d["config"]["parallelism"] == "phi_y-slab x2"
     assert abs(d["ms_per_step"] * 1e-3 * d["value"] - 128 * 131072) < 1e-3 * 128 * 131072
     assert d["roofline"]["kernel"] == "fused2_step_kernel" and "note" in d["roofline"]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: the process starts the two ranks itself
+    (before it touches a GPU), their one JSON line comes through, and so does their status."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--repeats", "2", "--g-grid-per-gpu", "65536"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["repeats"] == 2
+    assert "g-grid=131072" in d["config"]["workload"]
+    assert abs(d["ms_per_step"] * 1e-3 * d["value"] - 128 * 131072) < 1e-3 * 128 * 131072
+    # a failing rank's status comes back too
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
+                        "--g-grid-per-gpu", "4"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
+    assert r.returncode != 0

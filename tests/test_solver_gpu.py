@@ -365,7 +365,6 @@ def test_double_step_hands_out_the_rows_av_reads(slb, oracle, N, M, B, omega):
         a_ptrs = (C.c_void_p * 2)(rows[0].data_ptr(), rows[1].data_ptr())
         b_ptrs = (C.c_void_p * 2)(rows[0].data_ptr() + 4 * pitch, rows[1].data_ptr() + 4 * pitch)
         t_ptrs = (C.c_void_p * 2)(tot[0].data_ptr(), tot[1].data_ptr())
-        L.slb_av_sums_exact_n.argtypes = [C.POINTER(slb.Slab), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         assert L.slb_av_sums_exact_n(C.byref(slab), 2, a_ptrs, b_ptrs, t_ptrs) == 0
         for k in range(2):
             t_k = np.float32(orc.st.t)
