@@ -278,6 +278,25 @@ int slb_seq_sum(const float *x, int n, float *out);
  * terms that one thread added one by one (device, 2 ints; may be NULL). */
 int slb_seq_sum_stats(const float *x, int n, float *out, int *stats);
 
+/* av() for callers that cannot allocate device memory: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  av()
+ * keeps its reduction workspace (block partials of the tree sums, the totals handed from
+ * the sums to the running-average update) in memory it allocates on first use;
+ * slb_av_static() runs the same kernels in the same av mode with that workspace in a
+ * statically allocated device array (24 608 bytes on every GPU the library runs on, held
+ * until the process ends) and calls no hipMalloc, hipFree or other allocating routine.
+ * Same arguments as av() without `blocks`, same effect on av_data[0..5], bit for bit.
+ * Limit: g-grid <= SLB_AV_STATIC_MAX_COLUMNS (one workspace entry per 2048 columns);
+ * beyond it the call prints the reason and returns -1 without launching.  Returns 0, -1
+ * for an argument error, or a hipError_t value.  All calls on one GPU share that GPU's
+ * array: calls that overlap there (different streams, different threads) race; calls on
+ * one stream do not.  slb_static_init() looks the array's device address up for the
+ * current device (also done by the first slb_av_static() there); call it once per device
+ * at set-up if the first slb_av_static() would otherwise fall inside a graph capture. */
+#define SLB_AV_STATIC_MAX_COLUMNS 2097152
+int slb_static_init(void);
+int slb_av_static(float *a, float *b, float *av_data, float t);
+
 /* Stream for every launch of this library (a hipStream_t passed as void*). */
 void  slb_set_stream(void *hip_stream);
 void *slb_get_stream(void);

@@ -27,7 +27,7 @@ ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "Handle
                  "slb_av_sums_exact", "slb_av_sums_exact_n", "slb_av_sums_exact_from_n", "slb_av_update_exact", "slb_halo_pack", "slb_halo_unpack", "slb_halo_pack_segs", "slb_halo_unpack_segs", "slb_av_partial",
                  "slb_frame_values", "slb_seq_sum", "slb_seq_sum_stats",
                  "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream",
-                 "slb_set_tuning", "slb_version")
+                 "slb_set_tuning", "slb_version", "slb_static_init", "slb_av_static")
 ABI_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha",
                "PhiYmin", "PhiYmax", "host_B", "t_start", "host_dPhi", "host_dt",
                "host_bdt", "host_nu_tilde", "host_nu2", "host_nu",
@@ -104,6 +104,8 @@ def lib():
         L.slb_step_multi.argtypes = [C.POINTER(MultiGeom), fp, C.POINTER(C.c_void_p * 4), C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p * 4), C.POINTER(C.c_float)]
         L.slb_step_multi.restype = i
+        L.slb_static_init.argtypes, L.slb_static_init.restype = [], i
+        L.slb_av_static.argtypes, L.slb_av_static.restype = [fp, fp, fp, f], i
         L.slb_halo_pack.argtypes = [fp, fp, i, i, i, i, fp]
         L.slb_halo_pack.restype = i
         L.slb_halo_unpack.argtypes = [fp, fp, i, i, i, i, fp]

@@ -41,6 +41,7 @@ double     *g_ws = nullptr;          // reduction workspace, allocated once
 int         g_ws_device = -1;
 constexpr int kMaxAvBlocks = 1024;
 constexpr int kAvColsPerBlock = 256 * 8;   // columns a block of the tree sums takes per pass
+static_assert(SLB_AV_STATIC_MAX_COLUMNS == kMaxAvBlocks * kAvColsPerBlock, "slb_abi.h states the limit");
 
 struct SweepArgs {
   const float *a0, *a_c, *b_c, *a_s, *b_s;
@@ -1542,6 +1543,34 @@ int ensure_workspace()
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// av() for callers that cannot allocate (code under HIP graph capture, serving
+// loops, harnesses that forbid hipMalloc): the reduction workspace lives in a
+// statically allocated device array instead of a hipMalloc'ed one.  Every GPU
+// the library runs on holds its own copy of the array (kWsDoubles * 8 = 24 608
+// bytes) until the process ends.  In host code the array's name is only a
+// handle: its device address is looked up once per device and kept.
+// ---------------------------------------------------------------------------
+static __device__ __align__(256) double scratch[kWsDoubles];
+double *g_scratch_of[kMaxDevices] = {};                  // device address of `scratch`, per device
+
+int static_workspace(double **ws)
+{
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= kMaxDevices) { fprintf(stderr, "libslb2d: device index %d not supported\n", dev); return -1; }
+  if (!g_scratch_of[dev]) {
+    double *ptr = nullptr;
+    e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return (int)e;
+    if (!ptr) return -1;
+    g_scratch_of[dev] = ptr;
+  }
+  *ws = g_scratch_of[dev];
+  return 0;
+}
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Rows per workgroup when the caller leaves it to the library.  A wave walks its rows one
@@ -2132,6 +2161,29 @@ void av(int blocks, float *a, float *b, float *av_data, float t)
   if (rc == 0) rc = av_with_workspace(g_ws, a, b, av_data, t);
   if (rc > 0) HandleError(rc, __FILE__, __LINE__);
   if (rc < 0) exit(EXIT_FAILURE);
+}
+
+int slb_static_init(void)
+{
+  double *ws = nullptr;
+  return static_workspace(&ws);
+}
+
+int slb_av_static(float *a, float *b, float *av_data, float t)
+{
+  if (!g_phys.loaded) { fprintf(stderr, "slb_av_static: load_data() has not been called\n"); return -1; }
+  if (!a || !b || !av_data) { fprintf(stderr, "slb_av_static: null array\n"); return -1; }
+  // the static workspace holds one partial per block of the tree sums and a block takes
+  // kAvColsPerBlock columns: that many columns at most, whichever way the sums are formed
+  if (g_phys.TMSIZE - 1 > SLB_AV_STATIC_MAX_COLUMNS) {
+    fprintf(stderr, "slb_av_static: g-grid %d is beyond the %d columns the static workspace is sized for; use av()\n",
+            g_phys.TMSIZE - 1, SLB_AV_STATIC_MAX_COLUMNS);
+    return -1;
+  }
+  double *ws = nullptr;
+  int rc = static_workspace(&ws);
+  if (rc == 0) rc = av_with_workspace(ws, a, b, av_data, t);
+  return rc;
 }
 
 }  // extern "C"
