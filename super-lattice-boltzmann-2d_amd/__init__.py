@@ -13,7 +13,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslb2d.so")
+# SLB_LIB: another build of the same library (A/B timing of kernel variants); default: in-tree
+LIB_PATH = os.environ.get("SLB_LIB") or os.path.join(_HERE, "libslb2d.so")
 
 _FLOAT_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha",
                   "PhiYmin", "PhiYmax", "host_B", "t_start", "host_dPhi", "host_dt",

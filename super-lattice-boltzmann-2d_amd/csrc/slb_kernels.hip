@@ -387,11 +387,11 @@ struct FusedArgs {
 // value of lane-1 / lane+1 (lane 0 / lane 63 get 0; they never use it)
 __device__ __forceinline__ float from_left_lane(float v)
 {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float from_right_lane(float v)
 {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
 // own[0..3] -> e[0..5] = columns j-1 .. j+4 using the adjacent lanes
@@ -615,8 +615,14 @@ struct Fused2Args {
   float *rows1, *rows2;                      // ROWS: [3][pitch] each: a rows 0, 1 and b row 1 of stage A's / C's output
   float E_dc, E_omega, B, dt, dPhi, PhiYmin, nu, nu2, nu_tilde, bdt;
   float c[8];                                // cosines: stage A 0,1  B 2,3  C 4,5  D 6,7
-  int N, pitch, m_offset, n_chunk, jj0;
+  int N, pitch, m_offset, jj0;
   int jf[4], jl[4];                          // columns stage A, B, C, D produce
+  // Launch schedule.  Workgroups are dispatched in the order of their index; phase p takes
+  // indices wg_begin[p] .. wg_begin[p+1]-1 and deals them out over the column-strip groups
+  // g0[p] .. g0[p]+ng[p]-1 (one group = the strips of one workgroup), fastest, and the row
+  // chunks of length len[p] that rows 0..N-1 are cut into.  Indices a phase was padded with
+  // (so that the next phase starts on a multiple of 8) do nothing.
+  int n_phase, wg_begin[4], g0[3], ng[3], len[3];
 };
 
 // ROWS: the three rows av() reads (a rows 0 and 1, b row 1) of BOTH new main lattices are
@@ -632,9 +638,18 @@ fused2_step_kernel(const Fused2Args p)
   // column strips overlap by their halo lanes, so strips that are adjacent in memory are
   // given to workgroups of the same XCD: the shared lines are then served by that XCD's L2.
   // (Placement only changes where re-reads are served from, never what is computed.)
-  int bx = blockIdx.x;
-  const int per_xcd = gridDim.x >> 3;
+  int id = blockIdx.x, ph = 0;
+  if (p.n_phase > 1 && id >= p.wg_begin[1]) ph = 1;
+  if (p.n_phase > 2 && id >= p.wg_begin[2]) ph = 2;
+  id -= p.wg_begin[ph];
+  const int ng = p.ng[ph];
+  const int chunk = id / ng;
+  int bx = id - chunk * ng;
+  const int n0 = chunk * p.len[ph];
+  if (n0 >= p.N) return;                                        // padding of the phase
+  const int per_xcd = ng >> 3;
   if (bx < (per_xcd << 3)) bx = (bx & 7) * per_xcd + (bx >> 3);
+  bx += p.g0[ph];
   const int wave = (bx * blockDim.x + threadIdx.x) >> 6;
   const int jj   = p.jj0 + (wave * 62 + lane - 1) * V;          // first own column (may be < 0)
   int j_hi = p.jl[0];
@@ -645,8 +660,7 @@ fused2_step_kernel(const Fused2Args p)
   const int jcl = jj < 0 ? 0 : (jj > p.pitch - V ? p.pitch - V : jj);
   const unsigned j = (unsigned)jcl;
 
-  const int n0 = blockIdx.y * p.n_chunk;
-  const int n1 = n0 + p.n_chunk < p.N ? n0 + p.n_chunk : p.N;
+  const int n1 = n0 + p.len[ph] < p.N ? n0 + p.len[ph] : p.N;
   // first row each stage has to form so that D can form rows n0..n1-1
   const int c_lo = n0 > 1 ? n0 - 1 : 0, b_lo = n0 > 2 ? n0 - 2 : 0, a_lo = n0 > 3 ? n0 - 3 : 0;
   const int r_end = n1 + 2;                      // D forms row n1-1 when A stands at n1+2
@@ -1626,8 +1640,34 @@ int launch_fused(FusedArgs &args, int block)
   return (int)hipGetLastError();
 }
 
+// workgroups of `block` threads of a kernel that the current device holds at once (0 if unknown)
+template <class K>
+int resident_workgroups(K kernel, int block)
+{
+  static int cache[kMaxDevices][5] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+  int &slot = cache[dev][block / 64];
+  if (slot == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    slot = per_cu * cus > 0 ? per_cu * cus : -1;
+  }
+  return slot > 0 ? slot : 0;
+}
+
+// n_chunk > 0: every strip group is cut into chunks of n_chunk rows (one phase).
+// n_chunk == 0 (the library chooses): on a lattice wide enough for many rounds of
+// workgroups, as many strip groups as fill the device a whole number of times take all
+// their rows in one workgroup each -- such a workgroup reads every input row once and forms
+// no row twice -- and only the groups left over are cut into chunks (`tail_chunk` rows);
+// narrower lattices are cut into chunks of `tail_chunk` rows throughout.
 template <int MINW, bool DIAG = false, bool ROWS = false>
-int launch_fused2(Fused2Args &args, int block)
+int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
 {
   int lo = args.jf[0], hi = args.jl[0];
   for (int q = 1; q < 4; q++) { lo = args.jf[q] < lo ? args.jf[q] : lo; hi = args.jl[q] > hi ? args.jl[q] : hi; }
@@ -1635,8 +1675,31 @@ int launch_fused2(Fused2Args &args, int block)
   const int per_wave = 62 * 4;
   const int waves = (hi + 1 - args.jj0 + per_wave - 1) / per_wave;
   const int wpb = block / 64;
-  dim3 grid((waves + wpb - 1) / wpb, (args.N + args.n_chunk - 1) / args.n_chunk);
-  hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS>), grid, dim3(block), 0, g_stream, args);
+  const int groups = (waves + wpb - 1) / wpb;
+  auto chunks_of = [&](int len) { return (args.N + len - 1) / len; };
+  const int slots = n_chunk > 0 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS>, block);
+  // (measured on MI355X, 128 rows: with 11 rounds of workgroups -- 2^23 columns -- whole
+  // groups first is 2 % faster than cutting every group; with 1.4 rounds -- 2^20 columns --
+  // it is no faster although it moves 5 % fewer bytes, and at 512 rows 5 % slower: the
+  // leftover groups then start late and run at a fraction of the device's bandwidth)
+  const int whole = slots > 0 && groups >= 4 * slots ? groups / slots * slots : 0;
+  if (n_chunk <= 0 && whole == 0) n_chunk = tail_chunk;
+  if (n_chunk > 0) {
+    if (n_chunk > args.N) n_chunk = args.N;
+    args.n_phase = 1;
+    args.g0[0] = 0; args.ng[0] = groups; args.len[0] = n_chunk;
+    args.wg_begin[0] = 0; args.wg_begin[1] = groups * chunks_of(n_chunk);
+  } else {
+    if (tail_chunk > args.N) tail_chunk = args.N;
+    args.n_phase = whole < groups ? 2 : 1;
+    args.g0[0] = 0; args.ng[0] = whole; args.len[0] = args.N;
+    args.wg_begin[0] = 0; args.wg_begin[1] = (whole + 7) / 8 * 8;
+    args.g0[1] = whole; args.ng[1] = groups - whole; args.len[1] = tail_chunk;
+    args.wg_begin[2] = args.wg_begin[1] + (groups - whole) * chunks_of(tail_chunk);
+  }
+  for (int k = args.n_phase; k < 3; k++) { args.g0[k] = 0; args.ng[k] = 1; args.len[k] = args.N; args.wg_begin[k + 1] = args.wg_begin[k]; }
+  hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS>), dim3(args.wg_begin[args.n_phase]), dim3(block), 0,
+                     g_stream, args);
   return (int)hipGetLastError();
 }
 
@@ -1866,33 +1929,29 @@ int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
 
   const int block = g_block > 0 ? g_block : 256;
   if (block % 64 != 0 || block > 256) { fprintf(stderr, "slb_step_fused2: block must be 64, 128, 192 or 256\n"); return -1; }
-  // each chunk re-forms three rows of stage A above and below itself (two of B, one of C);
-  // 32-row chunks measured fastest at n-harmonics 128, g-grid 2^20
-  int n_chunk = g_n_chunk;
-  if (n_chunk <= 0) {
-    int lo = s.jf[0], hi = s.jl[0];
-    for (int q = 1; q < 4; q++) { lo = s.jf[q] < lo ? s.jf[q] : lo; hi = s.jl[q] > hi ? s.jl[q] : hi; }
-    // Rows per workgroup on a lattice wide enough to fill the device: 7/16 of the rows, so that
-    // two long chunks are followed by a short one (56, 56, 16 at 128 rows).  Workgroups are
-    // dispatched chunk after chunk; the short ones at the end fill the compute units that
-    // equal chunks leave idle while the last of them finish (measured at 2^20 columns: 1.113 ms
-    // against 1.146 ms for four chunks of 32; 224 rows at 512, 112 at 256 likewise).  With eight
-    // times as many columns the end of the launch no longer matters and halves are quicker.
-    int cap = 32;
-    if (s.N >= 128) cap = (hi - lo + 1 >= (1 << 22)) ? s.N / 2 : (7 * s.N + 15) / 16;
-    n_chunk = auto_chunk(s.N, hi - lo + 1, 248, block, cap);
-  }
-  if (n_chunk > s.N) n_chunk = s.N;
-  s.n_chunk = n_chunk;
-  if (rows_first) return launch_fused2<3, false, true>(s, block);
+  // Each chunk of rows re-forms three rows of stage A above and below itself (two of B, one
+  // of C) and re-reads their inputs, so chunks are a cost; they are there to fill the device.
+  int lo = s.jf[0], hi = s.jl[0];
+  for (int q = 1; q < 4; q++) { lo = s.jf[q] < lo ? s.jf[q] : lo; hi = s.jl[q] > hi ? s.jl[q] : hi; }
+  // Rows per workgroup where strip groups have to be cut (see launch_fused2): 7/16 of the rows,
+  // so that two long chunks are followed by a short one (56, 56, 16 at 128 rows).  Workgroups
+  // are dispatched chunk after chunk; the short ones at the end fill the compute units that
+  // equal chunks leave idle while the last of them finish (measured at 2^20 columns with every
+  // group cut: 1.113 ms against 1.146 ms for four chunks of 32; 224 rows at 512, 112 at 256
+  // likewise).  Lattices narrower than about a thousand workgroups get shorter chunks.
+  int cap = 32;
+  if (s.N >= 128) cap = (7 * s.N + 15) / 16;
+  const int tail_chunk = auto_chunk(s.N, hi - lo + 1, 248, block, cap);
+  // tuning variant 26: every strip group cut into chunks, as for a narrow lattice
+  int n_chunk = g_n_chunk > 0 ? g_n_chunk : (g_variant == 26 || s.N < 64 ? tail_chunk : 0);
+  if (rows_first) return launch_fused2<3, false, true>(s, block, n_chunk, tail_chunk);
   switch (g_variant) {
-    case 21: return launch_fused2<2>(s, block);           // register budget of 2, 3 (default), 4 waves per SIMD
-    case 23: return launch_fused2<3>(s, block);
-    case 25: return launch_fused2<4>(s, block);
+    case 21: return launch_fused2<2>(s, block, n_chunk, tail_chunk);   // register budget of 2, 3 (default), 4 waves per SIMD
+    case 25: return launch_fused2<4>(s, block, n_chunk, tail_chunk);
 #ifdef SLB_TIMING_VARIANTS
-    case 98: return launch_fused2<3, true>(s, block);   // arithmetic removed: memory floor, wrong results
+    case 98: return launch_fused2<3, true>(s, block, n_chunk, tail_chunk);   // arithmetic removed: memory floor, wrong results
 #endif
-    default: return launch_fused2<3>(s, block);
+    default: return launch_fused2<3>(s, block, n_chunk, tail_chunk);
   }
 }
 

@@ -36,6 +36,40 @@ void slb_derive_and_load(void)
   load_data();
 }
 
+/* Lattice arrays are allocated one by one, and the k-th array of a run starts k*4096 bytes
+ * into its allocation: the sweeps read the same cell of five arrays and write it in two or
+ * four more at the same moment, and large allocations all start at the same offset within
+ * the memory channels' interleaving pattern.  Measured on MI355X at n-harmonics 128,
+ * g-grid 2^20: a two-sweep launch takes 0.670 ms with 4096 bytes between the starts
+ * (0.675-0.684 with 1024-8192) against 0.708 ms with none; the double step is unaffected.
+ * SLB_STAGGER=<bytes> (a multiple of 16) sets another distance. */
+#define SLB_MAX_ALLOCS 64
+static struct { void *user, *base; } g_allocs[SLB_MAX_ALLOCS];
+static int g_alloc_seq = 0;
+
+static hipError_t lattice_alloc(float **out, size_t bytes)
+{
+  const char *e = getenv("SLB_STAGGER");
+  const size_t stagger = e ? (size_t)atol(e) / 16 * 16 : 4096;
+  const size_t off = stagger * (size_t)(g_alloc_seq++ % 16);
+  void *base = NULL;
+  hipError_t rc = hipMalloc(&base, bytes + off);
+  if (rc != hipSuccess) return rc;
+  *out = (float *)((char *)base + off);
+  for (int i = 0; i < SLB_MAX_ALLOCS; i++)
+    if (!g_allocs[i].user) { g_allocs[i].user = *out; g_allocs[i].base = base; return hipSuccess; }
+  hipFree(base);
+  return hipErrorOutOfMemory;
+}
+
+static void lattice_free(float *p)
+{
+  if (!p) return;
+  for (int i = 0; i < SLB_MAX_ALLOCS; i++)
+    if (g_allocs[i].user == p) { hipFree(g_allocs[i].base); g_allocs[i].user = g_allocs[i].base = NULL; return; }
+  hipFree(p);
+}
+
 static float phi_y_of(int m) { return PhiYmin + host_dPhi * (m - 1); }
 
 /* Equilibrium coefficients for global columns m_offset .. m_offset+cols-1
@@ -99,12 +133,12 @@ slb_solver *slb_solver_create(int rank, int nranks)
   if (!h) { fprintf(stderr, "slb_solver_create: out of host memory\n"); free(s); return NULL; }
   fill_a0(h, s->pitch, s->m_offset, cols);
 
-  HIP_OK(hipMalloc((void **)&s->a0, bytes));
+  HIP_OK(lattice_alloc(&s->a0, bytes));
   HIP_OK(hipMemcpy(s->a0, h, bytes, hipMemcpyHostToDevice));
   free(h);
   for (int i = 0; i < 4; i++) {
-    HIP_OK(hipMalloc((void **)&s->a[i], bytes));
-    HIP_OK(hipMalloc((void **)&s->b[i], bytes));
+    HIP_OK(lattice_alloc(&s->a[i], bytes));
+    HIP_OK(lattice_alloc(&s->b[i], bytes));
     HIP_OK(hipMemset(s->a[i], 0, bytes));
     HIP_OK(hipMemset(s->b[i], 0, bytes));
   }
@@ -123,10 +157,10 @@ slb_solver *slb_solver_create(int rank, int nranks)
 void slb_solver_destroy(slb_solver *s)
 {
   if (!s) return;
-  hipFree(s->a0);
-  for (int i = 0; i < 4; i++) { hipFree(s->a[i]); hipFree(s->b[i]); }
+  lattice_free(s->a0);
+  for (int i = 0; i < 4; i++) { lattice_free(s->a[i]); lattice_free(s->b[i]); }
   hipFree(s->av_data); hipFree(s->sums); hipFree(s->halo_buf);
-  if (s->spare_a) { hipFree(s->spare_a); hipFree(s->spare_b); hipFree(s->spare_ah); hipFree(s->spare_bh); }
+  lattice_free(s->spare_a); lattice_free(s->spare_b); lattice_free(s->spare_ah); lattice_free(s->spare_bh);
   free(s);
 }
 
@@ -258,10 +292,10 @@ static void sync_spares(slb_solver *s)
 {
   const size_t bytes = (size_t)(s->N + 1) * (size_t)s->pitch * sizeof(float);
   if (!s->spare_a) {
-    HIP_OK(hipMalloc((void **)&s->spare_a, bytes));
-    HIP_OK(hipMalloc((void **)&s->spare_b, bytes));
-    HIP_OK(hipMalloc((void **)&s->spare_ah, bytes));
-    HIP_OK(hipMalloc((void **)&s->spare_bh, bytes));
+    HIP_OK(lattice_alloc(&s->spare_a, bytes));
+    HIP_OK(lattice_alloc(&s->spare_b, bytes));
+    HIP_OK(lattice_alloc(&s->spare_ah, bytes));
+    HIP_OK(lattice_alloc(&s->spare_bh, bytes));
   }
   hipStream_t st = (hipStream_t)slb_get_stream();
   HIP_OK(hipMemcpyAsync(s->spare_a,  s->a[s->current],    bytes, hipMemcpyDeviceToDevice, st));
