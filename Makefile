@@ -17,7 +17,7 @@ HIPFLAGS := --offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 -Wall $
 CFLAGS   := -std=gnu99 -O3 -fPIC -ffp-contract=off -Wall -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include
 
 HOST_SRC := $(PKG)/host/slb_globals.c $(PKG)/host/slb_bessel.c $(PKG)/host/slb_cli.c \
-            $(PKG)/host/slb_solver.c $(PKG)/host/slb_main.c
+            $(PKG)/host/slb_solver.c $(PKG)/host/slb_main.c $(PKG)/host/slb_link.c $(PKG)/host/slb_slabs.c
 HOST_OBJ := $(HOST_SRC:.c=.o)
 HDRS     := include/slb_abi.h $(PKG)/host/slb_host.h
 
@@ -32,7 +32,7 @@ $(PKG)/host/%.o: $(PKG)/host/%.c $(HDRS)
 	$(CC) $(CFLAGS) -c $< -o $@
 
 $(LIB): $(PKG)/csrc/slb_kernels.o $(HOST_OBJ)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lm
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lm -ldl -Wl,-rpath,$(ROCM)/lib
 
 bin/boltzmann_solver: $(PKG)/host/boltzmann_solver.c $(LIB)
 	@mkdir -p bin

@@ -275,11 +275,21 @@ def main():
         drv = importlib.import_module("super-lattice-boltzmann-2d_amd.dist")
         driver = args.driver
         if driver == "auto":
-            driver = "c" if (backend == "nccl" and hasattr(drv, "CSlabRun")) else "torch"
+            driver = "c" if (backend == "nccl" and args.form == "double") else "torch"
+        if driver == "c" and (backend != "nccl" or args.form != "double"):
+            raise SystemExit("--driver c runs the double step over RCCL only")
+        run = None
         if driver == "c":
-            run = drv.CSlabRun(slb, rank, world, backend)
-            ranks_seen = run.ranks_seen()
-        else:
+            try:
+                run = drv.CSlabRun(slb, rank, world, backend)
+                ranks_seen = run.ranks_seen()
+            except RuntimeError as e:                    # raised on every rank alike
+                if args.driver == "c":
+                    raise
+                if rank == 0:
+                    sys.stderr.write(f"bench: C slab driver unavailable ({e}); using torch.distributed\n")
+                driver = "torch"
+        if run is None:
             run = drv.SlabRun(slb, rank, world)
         run.tiptoe()
 

@@ -188,6 +188,32 @@ def lib():
         L.slb_solver_get_rows.restype = i
         L.slb_solver_get_window.argtypes = [C.POINTER(SolverStruct), i, i, i, fp]
         L.slb_solver_get_window.restype = i
+        # several GPUs: links between processes and the slab time loop (host/slb_link.c, slb_slabs.c)
+        sz = C.c_size_t
+        L.slb_link_unique_id.argtypes, L.slb_link_unique_id.restype = [C.c_char_p], i
+        L.slb_link_open_rccl.argtypes, L.slb_link_open_rccl.restype = [i, i, C.c_char_p], vp
+        L.slb_link_open_fds.argtypes, L.slb_link_open_fds.restype = [i, i, C.POINTER(C.c_int)], vp
+        L.slb_link_ranks_seen.argtypes, L.slb_link_ranks_seen.restype = [vp], i
+        L.slb_link_transport.argtypes, L.slb_link_transport.restype = [vp], C.c_char_p
+        L.slb_link_begin.argtypes, L.slb_link_begin.restype = [vp], None
+        L.slb_link_send.argtypes, L.slb_link_send.restype = [vp, i, fp, sz, vp], None
+        L.slb_link_recv.argtypes, L.slb_link_recv.restype = [vp, i, fp, sz, vp], None
+        L.slb_link_end.argtypes, L.slb_link_end.restype = [vp, vp], None
+        L.slb_link_close.argtypes, L.slb_link_close.restype = [vp], None
+        L.slb_slabs_create.argtypes, L.slb_slabs_create.restype = [i, i, vp], vp
+        L.slb_slabs_destroy.argtypes, L.slb_slabs_destroy.restype = [vp], None
+        L.slb_slabs_solver.argtypes, L.slb_slabs_solver.restype = [vp], C.POINTER(SolverStruct)
+        L.slb_slabs_main_stream.argtypes, L.slb_slabs_main_stream.restype = [vp], vp
+        L.slb_slabs_ranks_seen.argtypes, L.slb_slabs_ranks_seen.restype = [vp], i
+        L.slb_slabs_tiptoe.argtypes, L.slb_slabs_tiptoe.restype = [vp], None
+        L.slb_slabs_double_step.argtypes, L.slb_slabs_double_step.restype = [vp, fp, fp], None
+        L.slb_slabs_last_step.argtypes, L.slb_slabs_last_step.restype = [vp], None
+        L.slb_slabs_join.argtypes, L.slb_slabs_join.restype = [vp], None
+        L.slb_slabs_av_rows.argtypes, L.slb_slabs_av_rows.restype = [vp, i, C.POINTER(C.c_void_p * 2)], None
+        L.slb_slabs_av_submit.argtypes, L.slb_slabs_av_submit.restype = [vp, i, C.POINTER(C.c_float), i], None
+        L.slb_slabs_av_submit_current.argtypes, L.slb_slabs_av_submit_current.restype = [vp, f], None
+        L.slb_slabs_av_finish.argtypes, L.slb_slabs_av_finish.restype = [vp, C.POINTER(C.c_float * 6)], None
+        L.slb_slabs_gather_rows.argtypes, L.slb_slabs_gather_rows.restype = [vp, i, i, i, fp], None
         _lib = L
     return _lib
 

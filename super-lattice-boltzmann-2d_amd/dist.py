@@ -607,3 +607,62 @@ class ExactAvChain:
         if self.world > 1:
             dist.broadcast(host, src=self.world - 1, group=self.group)
         return host.numpy().copy()
+
+
+class CSlabRun:
+    """The slab time loop of host/slb_slabs.c -- launch order, halo messages and the av chain
+    in C, RCCL called from C -- for a process that torch.distributed.run started: the same
+    tiptoe() / double_step() / close() as SlabRun.  torch.distributed only hands rank 0's RCCL
+    identifier to the other ranks.  torch's current stream becomes the loop's main stream, so
+    events recorded by the caller bracket the interior launches."""
+
+    def __init__(self, slb, rank, world, backend="nccl"):
+        self.slb, self.rank, self.world = slb, rank, world
+        L = slb.lib()
+        self.link = None
+        if world > 1:
+            if backend != "nccl":
+                raise RuntimeError("CSlabRun moves its messages over RCCL; rehearsals on one GPU use "
+                                   "SlabRun (gloo) or the C program's own ranks= mode")
+            ident = C.create_string_buffer(128)
+            ok = rank != 0 or L.slb_link_unique_id(ident) == 0
+            box = [ident.raw if ok else None]
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is None:                      # every rank learns of it and can fall back together
+                raise RuntimeError("ncclGetUniqueId failed on rank 0 (is librccl.so.1 on the library path?)")
+            self.link = L.slb_link_open_rccl(rank, world, box[0])
+            if not self.link:
+                raise RuntimeError("slb_link_open_rccl failed")
+        self.r = L.slb_slabs_create(rank, world, self.link)
+        if not self.r:
+            raise RuntimeError("slb_slabs_create failed")
+        self.stream = torch.cuda.ExternalStream(L.slb_slabs_main_stream(self.r))
+        torch.cuda.set_stream(self.stream)
+
+    @property
+    def s(self):
+        return self.slb.lib().slb_slabs_solver(self.r).contents
+
+    def ranks_seen(self):
+        return self.slb.lib().slb_slabs_ranks_seen(self.r)
+
+    def tiptoe(self):
+        self.slb.lib().slb_slabs_tiptoe(self.r)
+
+    def double_step(self):
+        self.slb.lib().slb_slabs_double_step(self.r, None, None)
+
+    def last_step(self):
+        self.slb.lib().slb_slabs_last_step(self.r)
+
+    def join(self):
+        self.slb.lib().slb_slabs_join(self.r)
+
+    def close(self):
+        L = self.slb.lib()
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        L.slb_slabs_destroy(self.r)
+        if self.link:
+            L.slb_link_close(self.link)
+        self.r = self.link = None

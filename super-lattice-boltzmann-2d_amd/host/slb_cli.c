@@ -37,6 +37,7 @@ static const struct option options[] = {
   {"read-from",   K_STR,   &rf_name,      0},
   {"quiet",       K_FLAG,  &quiet,        0},
   {"device",      K_INT,   &device,       0},
+  {"ranks",       K_INT,   &ranks,        0},   /* not in the reference: phi_y slabs, one process per GPU */
   {"o",           K_STR,   &out_file,     0},
 };
 #define N_OPTIONS ((int)(sizeof(options) / sizeof(options[0])))

@@ -31,3 +31,4 @@ int   host_M = 3069;
 int   MSIZE, PADDED_MSIZE, MP1, host_TMSIZE, NSIZE;
 float host_dt = 0.001;
 float host_bdt, host_nu_tilde, host_nu2, host_nu;
+int   ranks = 1;            /* ranks=: processes (GPUs) of the run; not in the reference */

@@ -368,6 +368,9 @@ void slb_close_output(void)
 int slb_main(int argc, char **argv)
 {
   parse_cmd(argc, argv);
+  /* ranks=N: N processes, one per GPU, each with a phi_y slab of the lattice (forked
+   * before anything here has touched a GPU) */
+  if (ranks != 1) return slb_slab_main(ranks);
   HIP_OK(hipSetDevice(device));
 
   float T = host_omega > 0 ? (2 * SLB_PI / host_omega) : 0;   /* period of the a/c field */

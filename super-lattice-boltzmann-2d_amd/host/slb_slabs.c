@@ -1,0 +1,610 @@
+/*
+ * slb_slabs.c -- the time loop over phi_y slabs, one process per GPU, in C: launch order,
+ * halo columns and the chain of running sums of av(), with the messages going through
+ * slb_link (RCCL send/recv on a HIP stream, or sockets for rehearsals on one GPU).
+ * The reference runs on one GPU; the loop this spreads over several is
+ * reference src/boltzmann_solver.c:196-302, its display=4 record :348-380.
+ *
+ * Per double step (two loop iterations per launch, slb_step_fused2) and slab:
+ *
+ *   side stream:  edge column ranges -> pack -> { send/recv 7 columns per neighbour,
+ *                 + totals of av() on their way down the chain } -> unpack
+ *   main stream:  interior column range
+ *
+ * Each stream waits for the other's PREVIOUS double step only (results go to the spare
+ * arrays), so interior launches follow each other without a gap and the few-KB messages
+ * travel meanwhile.  Lattices are bit-identical to a single-GPU run.
+ *
+ * av() over slabs: the reference's three sums are ONE float running sum over all columns
+ * (reference: src/boltzmann_c_solver.c:413-437), so slab r starts from the totals slab r-1
+ * ended with.  The three rows the sums read are handed out by the double-step launches; the
+ * iterations of AVC_BATCH double steps form a batch whose sums run in one launch on a third
+ * stream.  A batch's totals leave rank r for rank r+1 in the message group of the
+ * AVC_LAG*(r+1)-th exchange after the batch was complete -- a fixed schedule every rank
+ * derives by itself, so the few floats ride along with the halo messages, nothing is polled
+ * and no rank ever waits on the host.  The last rank applies the running-average updates in
+ * step order.
+ */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <sys/wait.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "slb_host.h"
+
+#define HIP_OK(call) HandleError((int)(call), __FILE__, __LINE__)
+
+#define AVC_BATCH 4                 /* double steps per launch of the sums (8 lattices)           */
+#define AVC_LAG   4                 /* exchanges between a batch's arrival on a rank and its leaving */
+#define AVC_SETS  8                 /* lattices per batch at most                                  */
+
+typedef struct {
+  float *rows[AVC_SETS];            /* [3][pitch] each: a rows 0, 1 and b row 1                    */
+  float  t[AVC_SETS];               /* loop times of the lattices                                  */
+  int    n;                         /* lattices gathered                                           */
+  int    steps;                     /* double steps (or single steps) gathered                     */
+  long   ready;                     /* exchange count when the batch was complete; -1: still open  */
+  float *init, *tot;                /* device, 3 floats per lattice                                */
+  hipEvent_t done;                  /* sums (and on the last rank the updates) finished            */
+  int    summed, sent;
+} av_batch;
+
+struct slb_slabs {
+  slb_solver *s;
+  slb_link   *link;
+  int rank, nranks, left, right;
+  hipStream_t main, side, av;
+  hipEvent_t  ev_main, ev_side, ev_x;
+  int   side_busy;
+  float *send2[2], *recv2[2];       /* a double step's message per side: 2*7*(N+1) floats          */
+  float *send4[2], *recv4[2];       /* 4 columns of one lattice: 2*4*(N+1) floats                  */
+  long  exchanges;                  /* message groups so far (the clock of the av schedule)        */
+  /* av chain */
+  av_batch *ring;                   /* ring of batches                                             */
+  int   ring_n;
+  long  batch_open;                 /* index of the batch being filled                             */
+  long  batch_next_sum;             /* first batch whose sums have not been launched               */
+  long  batch_next_send;            /* first batch whose totals have not left                      */
+  float *av_data;                   /* device, 6 floats (meaningful on the last rank)              */
+};
+
+static void check(int rc, const char *what)
+{
+  if (rc > 0) HandleError(rc, __FILE__, __LINE__);
+  if (rc < 0) { fprintf(stderr, "ERROR: %s was refused\n", what); exit(EXIT_FAILURE); }
+}
+
+static av_batch *batch_at(slb_slabs *r, long b) { return &r->ring[b % r->ring_n]; }
+
+slb_slabs *slb_slabs_create(int rank, int nranks, slb_link *link)
+{
+  if (nranks > 1 && !link) { fprintf(stderr, "slb_slabs_create: %d ranks need a link\n", nranks); return NULL; }
+  slb_slabs *r = (slb_slabs *)calloc(1, sizeof(*r));
+  if (!r) return NULL;
+  r->rank = rank; r->nranks = nranks; r->link = link;
+  r->left = rank > 0 ? rank - 1 : -1;
+  r->right = rank < nranks - 1 ? rank + 1 : -1;
+  r->s = slb_solver_create(rank, nranks);
+  if (!r->s) { free(r); return NULL; }
+  /* not the legacy null stream: its implicit synchronisation with other streams would
+   * serialise the halo messages with the interior launches */
+  HIP_OK(hipStreamCreateWithFlags(&r->main, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&r->av, hipStreamNonBlocking));
+  HIP_OK(hipEventCreateWithFlags(&r->ev_main, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&r->ev_side, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&r->ev_x, hipEventDisableTiming));
+  const size_t col = sizeof(float) * 2 * (size_t)(r->s->N + 1);
+  for (int side = 0; side < 2; side++) {
+    HIP_OK(hipMalloc((void **)&r->send2[side], 7 * col));
+    HIP_OK(hipMalloc((void **)&r->recv2[side], 7 * col));
+    HIP_OK(hipMalloc((void **)&r->send4[side], 4 * col));
+    HIP_OK(hipMalloc((void **)&r->recv4[side], 4 * col));
+  }
+  HIP_OK(hipMalloc((void **)&r->av_data, 6 * sizeof(float)));
+  HIP_OK(hipMemset(r->av_data, 0, 6 * sizeof(float)));
+  /* batches alive at once: one being filled, AVC_LAG exchanges per rank upstream on their
+   * way here, one being summed, one waiting to leave */
+  r->ring_n = AVC_LAG * nranks / AVC_BATCH + 4;
+  r->ring = (av_batch *)calloc((size_t)r->ring_n, sizeof(av_batch));
+  for (int k = 0; k < r->ring_n; k++) {
+    r->ring[k].ready = -1;
+    HIP_OK(hipEventCreateWithFlags(&r->ring[k].done, hipEventDisableTiming));
+  }
+  HIP_OK(hipDeviceSynchronize());
+  slb_set_stream(r->main);
+  return r;
+}
+
+slb_solver *slb_slabs_solver(slb_slabs *r) { return r->s; }
+void *slb_slabs_main_stream(slb_slabs *r)  { return (void *)r->main; }
+float *slb_slabs_av_data(slb_slabs *r)     { return r->av_data; }
+
+/* ---- message groups ---------------------------------------------------------------------
+ * One group per exchange: the halo buffers given (NULL: none on that side), and whatever
+ * the av schedule has for this exchange.  Runs on the side stream. */
+static void av_launch_ready(slb_slabs *r);
+
+static void exchange(slb_slabs *r, float *const send[2], float *const recv[2], size_t n)
+{
+  const long e = r->exchanges;
+  av_batch *in = NULL, *out = NULL;
+  /* a batch arrives here AVC_LAG*rank exchanges after it was complete, and leaves AVC_LAG later */
+  /* (batches complete in order and `ready` grows from batch to batch, so only the oldest
+   * batch not yet summed, or not yet sent, can be due) */
+  if (r->left >= 0 && r->batch_next_sum < r->batch_open) {
+    av_batch *b = batch_at(r, r->batch_next_sum);
+    if (b->ready + (long)AVC_LAG * r->rank == e) in = b;
+  }
+  if (r->right >= 0 && r->batch_next_send < r->batch_open) {
+    av_batch *b = batch_at(r, r->batch_next_send);
+    if (b->ready + (long)AVC_LAG * (r->rank + 1) == e) out = b;
+  }
+  if (r->nranks > 1) {
+    if (out) {
+      if (!out->summed) { fprintf(stderr, "ERROR: av chain: batch due to leave before its sums were started\n"); exit(EXIT_FAILURE); }
+      HIP_OK(hipStreamWaitEvent(r->side, out->done, 0));
+    }
+    slb_link_begin(r->link);
+    if (r->left >= 0 && send) {
+      slb_link_send(r->link, r->left, send[0], n, r->side);
+      slb_link_recv(r->link, r->left, recv[0], n, r->side);
+    }
+    if (r->right >= 0 && send) {
+      slb_link_send(r->link, r->right, send[1], n, r->side);
+      slb_link_recv(r->link, r->right, recv[1], n, r->side);
+    }
+    if (in)  slb_link_recv(r->link, r->left, in->init, 3 * (size_t)in->n, r->side);
+    if (out) slb_link_send(r->link, r->right, out->tot, 3 * (size_t)out->n, r->side);
+    slb_link_end(r->link, r->side);
+    if (out) { out->sent = 1; r->batch_next_send++; }
+  }
+  r->exchanges = e + 1;
+  if (in) {
+    HIP_OK(hipEventRecord(r->ev_x, r->side));
+    HIP_OK(hipStreamWaitEvent(r->av, r->ev_x, 0));
+    av_launch_ready(r);
+  }
+}
+
+/* ---- stepping --------------------------------------------------------------------------- */
+static void on_stream(hipStream_t st) { slb_set_stream((void *)st); }
+
+/* first half step, then the ghost columns of the new half-step lattice (the main
+ * lattice's are from the initial state) */
+void slb_slabs_tiptoe(slb_slabs *r)
+{
+  on_stream(r->side);
+  slb_solver_tiptoe(r->s);
+  for (int side = 0; side < 2; side++)
+    if ((side == 0 ? r->left : r->right) >= 0) check(slb_solver_halo_pack(r->s, 0, side, 4, r->send4[side]), "halo pack");
+  exchange(r, r->send4, r->recv4, 2 * 4 * (size_t)(r->s->N + 1));
+  for (int side = 0; side < 2; side++)
+    if ((side == 0 ? r->left : r->right) >= 0) check(slb_solver_halo_unpack(r->s, 0, side, 4, r->recv4[side]), "halo unpack");
+  HIP_OK(hipStreamSynchronize(r->side));
+  on_stream(r->main);
+}
+
+/* Two loop iterations.  rows_first / rows_second (both or neither): [3][pitch] device
+ * buffers that receive the rows av() reads of the main lattice after the first and after
+ * the second iteration, at this slab's columns. */
+void slb_slabs_double_step(slb_slabs *r, float *rows_first, float *rows_second)
+{
+  slb_solver *s = r->s;
+  float c[8];
+  slb_step2_cosines(s->t, c);
+  const int first = s->G, last_owned = s->G + s->W - 1;
+  const int lo = r->left >= 0 ? first + 4 : first;
+  const int hi = r->right >= 0 ? last_owned - 4 : last_owned;
+  if (r->nranks == 1) {
+    on_stream(r->main);
+    slb_solver_double_step_range_rows(s, lo, hi, c, rows_first, rows_second);
+    HIP_OK(hipEventRecord(r->ev_main, r->main));
+    exchange(r, NULL, NULL, 0);                       /* the clock of the av schedule ticks all the same */
+    slb_solver_double_step_finish(s);
+    return;
+  }
+  on_stream(r->main);
+  slb_solver_prepare_double_step(s);                  /* spare arrays, if stale, on the main stream */
+  /* halo chain: reads what the last interior launch wrote, writes the spare arrays' edge
+   * and ghost columns (which that launch read) */
+  if (!r->side_busy) HIP_OK(hipEventRecord(r->ev_main, r->main));
+  HIP_OK(hipStreamWaitEvent(r->side, r->ev_main, 0));
+  on_stream(r->side);
+  if (r->left >= 0)  slb_solver_double_step_range_rows(s, first, first + 3, c, rows_first, rows_second);
+  if (r->right >= 0) slb_solver_double_step_range_rows(s, last_owned - 3, last_owned, c, rows_first, rows_second);
+  check(slb_solver_halo_pack_double(s, r->left >= 0 ? r->send2[0] : NULL, r->right >= 0 ? r->send2[1] : NULL), "halo pack");
+  exchange(r, r->send2, r->recv2, 2 * 7 * (size_t)(s->N + 1));
+  /* interior: reads what the last halo chain wrote, writes the spare arrays' interior
+   * (which that chain read) */
+  if (r->side_busy) HIP_OK(hipStreamWaitEvent(r->main, r->ev_side, 0));
+  on_stream(r->main);
+  slb_solver_double_step_range_rows(s, lo, hi, c, rows_first, rows_second);
+  HIP_OK(hipEventRecord(r->ev_main, r->main));
+  on_stream(r->side);
+  check(slb_solver_halo_unpack_double(s, r->left >= 0 ? r->recv2[0] : NULL, r->right >= 0 ? r->recv2[1] : NULL), "halo unpack");
+  HIP_OK(hipEventRecord(r->ev_side, r->side));
+  r->side_busy = 1;
+  on_stream(r->main);
+  slb_solver_double_step_finish(s);                   /* the spares become the current lattices */
+}
+
+/* the main stream waits for the side stream's halo work (before anything but another
+ * double step touches the lattices) */
+void slb_slabs_join(slb_slabs *r)
+{
+  if (r->side_busy) {
+    HIP_OK(hipStreamWaitEvent(r->main, r->ev_side, 0));
+    r->side_busy = 0;
+  }
+  on_stream(r->main);
+}
+
+/* The LAST loop iteration of a run as one fused launch.  A slab forms the main sweep one
+ * column into its ghost zone itself, so nothing has to travel -- and nothing does: the
+ * ghost columns are stale afterwards, no further step may follow. */
+void slb_slabs_last_step(slb_slabs *r)
+{
+  slb_slabs_join(r);
+  slb_solver_step_fused(r->s);
+  HIP_OK(hipEventRecord(r->ev_main, r->main));
+}
+
+/* ---- av chain --------------------------------------------------------------------------- */
+static void batch_reset(slb_slabs *r, av_batch *b)
+{
+  const size_t row_bytes = sizeof(float) * 3 * (size_t)r->s->pitch;
+  if (!b->init) {
+    for (int k = 0; k < AVC_SETS; k++) {
+      HIP_OK(hipMalloc((void **)&b->rows[k], row_bytes));
+      HIP_OK(hipMemset(b->rows[k], 0, row_bytes));
+    }
+    HIP_OK(hipMalloc((void **)&b->init, sizeof(float) * 3 * AVC_SETS));
+    HIP_OK(hipMalloc((void **)&b->tot, sizeof(float) * 3 * AVC_SETS));
+    HIP_OK(hipDeviceSynchronize());
+  } else {
+    /* the buffers' last occupant has been summed before the time loop writes them again */
+    HIP_OK(hipStreamWaitEvent(r->main, b->done, 0));
+    HIP_OK(hipStreamWaitEvent(r->side, b->done, 0));
+  }
+  b->n = 0; b->steps = 0; b->ready = -1; b->summed = 0; b->sent = 0;
+}
+
+/* Row buffers for the next one or two lattices to average (the next double step's, or the
+ * last single step's): rows[0..n-1]. */
+void slb_slabs_av_rows(slb_slabs *r, int n, float *rows[2])
+{
+  av_batch *b = batch_at(r, r->batch_open);
+  if (b->ready >= 0 || !b->init) {
+    if (b->ready >= 0 && !(b->summed && (b->sent || r->right < 0))) {
+      fprintf(stderr, "ERROR: av chain: ring of %d batches is too short\n", r->ring_n);
+      exit(EXIT_FAILURE);
+    }
+    batch_reset(r, b);
+  }
+  for (int k = 0; k < n; k++) rows[k] = b->rows[b->n + k];
+}
+
+/* sums of every complete batch whose start values are here, in order */
+static void av_launch_ready(slb_slabs *r)
+{
+  for (;;) {
+    if (r->batch_next_sum >= r->batch_open) return;           /* only complete batches */
+    av_batch *b = batch_at(r, r->batch_next_sum);
+    if (r->left >= 0 && b->ready + (long)AVC_LAG * r->rank >= r->exchanges) return;   /* start values not here yet */
+    const float *a[AVC_SETS], *bb[AVC_SETS], *ini[AVC_SETS];
+    float *tot[AVC_SETS];
+    for (int k = 0; k < b->n; k++) {
+      a[k] = b->rows[k]; bb[k] = b->rows[k] + r->s->pitch;      /* b's row 1 is looked for at b + pitch = buffer row 2 */
+      ini[k] = r->left >= 0 ? b->init + 3 * k : NULL;
+      tot[k] = b->tot + 3 * k;
+    }
+    /* the rows were written by the interior launch and the edge launches of their double steps */
+    HIP_OK(hipStreamWaitEvent(r->av, r->ev_main, 0));
+    if (r->side_busy) HIP_OK(hipStreamWaitEvent(r->av, r->ev_side, 0));
+    void *before = slb_get_stream();
+    on_stream(r->av);
+    check(slb_av_sums_exact_from_n(&r->s->av_slab, b->n, a, bb, ini, tot), "the sums of av()");
+    if (r->right < 0)
+      for (int k = 0; k < b->n; k++) check(slb_av_update_exact(b->tot + 3 * k, r->av_data, b->t[k]), "the update of av()");
+    HIP_OK(hipEventRecord(b->done, r->av));
+    slb_set_stream(before);
+    b->summed = 1;
+    r->batch_next_sum++;
+  }
+}
+
+static void batch_close(slb_slabs *r)
+{
+  av_batch *b = batch_at(r, r->batch_open);
+  if (b->ready >= 0 || b->n == 0) return;
+  /* the exchange of the step that completed it; one exchange carries one batch, so a batch
+   * completed without an exchange of its own (the last single step) counts as the next one's */
+  long ready = r->exchanges - 1 >= 0 ? r->exchanges - 1 : 0;
+  if (r->batch_open > 0 && ready <= batch_at(r, r->batch_open - 1)->ready) ready = batch_at(r, r->batch_open - 1)->ready + 1;
+  b->ready = ready;
+  r->batch_open++;
+  if (r->left < 0) av_launch_ready(r);
+}
+
+/* The step that fills the buffers handed out by slb_slabs_av_rows() has been queued: n
+ * lattices at loop times t[0..n-1], buffers rows[skip .. skip+n-1] of that call (skip = 1:
+ * only the second iteration of a double step is averaged). */
+void slb_slabs_av_submit(slb_slabs *r, int n, const float *t, int skip)
+{
+  av_batch *b = batch_at(r, r->batch_open);
+  if (skip) {                                  /* the lattice to average sits in the second buffer */
+    float *x = b->rows[b->n]; b->rows[b->n] = b->rows[b->n + 1]; b->rows[b->n + 1] = x;
+  }
+  for (int k = 0; k < n; k++) b->t[b->n + k] = t[k];
+  b->n += n;
+  b->steps++;
+  if (b->steps >= AVC_BATCH || b->n + 2 > AVC_SETS) batch_close(r);
+}
+
+/* the three rows of the current main lattice -> the next row buffer, then as above */
+void slb_slabs_av_submit_current(slb_slabs *r, float t)
+{
+  float *rows[2];
+  slb_slabs_av_rows(r, 1, rows);
+  slb_slabs_join(r);
+  check(slb_solver_copy_av_rows(r->s, rows[0]), "copying the rows of av()");
+  HIP_OK(hipEventRecord(r->ev_main, r->main));
+  slb_slabs_av_submit(r, 1, &t, 0);
+}
+
+/* Everything submitted is summed and applied; av6 (host, 6 floats) receives the averaging
+ * data on rank 0 (other ranks: their own copy is meaningless and av6 is left alone). */
+void slb_slabs_av_finish(slb_slabs *r, float av6[6])
+{
+  batch_close(r);
+  /* empty exchanges until the last batch has passed the last rank */
+  const long last = r->batch_open - 1;
+  if (last >= 0) {
+    const long until = batch_at(r, last)->ready + (long)AVC_LAG * (r->nranks - 1);
+    on_stream(r->side);
+    while (r->exchanges <= until) exchange(r, NULL, NULL, 0);
+    on_stream(r->main);
+  }
+  HIP_OK(hipStreamSynchronize(r->side));
+  HIP_OK(hipStreamSynchronize(r->av));
+  if (r->nranks > 1) {
+    /* the last rank holds the result; rank 0 writes the record */
+    slb_link_begin(r->link);
+    if (r->rank == r->nranks - 1) slb_link_send(r->link, 0, r->av_data, 6, r->av);
+    if (r->rank == 0) slb_link_recv(r->link, r->nranks - 1, r->av_data, 6, r->av);
+    slb_link_end(r->link, r->av);
+    HIP_OK(hipStreamSynchronize(r->av));
+  }
+  if (r->rank == 0) HIP_OK(hipMemcpy(av6, r->av_data, 6 * sizeof(float), hipMemcpyDeviceToHost));
+}
+
+/* Rows [row0, row0+nrows) of device array `arr` (numbering of slb_solver_get_rows) over
+ * all slabs: on rank 0, dst receives nrows x (M+3) floats (global columns 0..M+2); other
+ * ranks send their columns and leave dst alone. */
+void slb_slabs_gather_rows(slb_slabs *r, int arr, int row0, int nrows, float *dst)
+{
+  slb_solver *s = r->s;
+  slb_slabs_join(r);
+  HIP_OK(hipStreamSynchronize(r->main));
+  HIP_OK(hipStreamSynchronize(r->side));
+  const float *src = arr == 0 ? s->a0 : (arr <= 4 ? s->a[arr - 1] : s->b[arr - 5]);
+  const int total = s->M + 3;
+  /* my columns: the owned ones, plus the global boundary columns on the outer slabs */
+  const int lo = r->rank == 0 ? s->G - 1 : s->G;
+  const int hi = r->rank == r->nranks - 1 ? s->G + s->W + 2 : s->G + s->W;     /* exclusive */
+  if (r->nranks == 1) {
+    HIP_OK(hipMemcpy2D(dst, sizeof(float) * total, src + (size_t)row0 * s->pitch + lo, sizeof(float) * s->pitch,
+                       sizeof(float) * (hi - lo), nrows, hipMemcpyDeviceToHost));
+    return;
+  }
+  float *all = NULL;
+  if (r->rank == 0) HIP_OK(hipMalloc((void **)&all, sizeof(float) * (size_t)nrows * total));
+  /* every rank can work out every other rank's columns; one message per row and rank */
+  const int base = s->M / r->nranks, rem = s->M % r->nranks;
+  if (r->rank == 0) {
+    for (int q = 1; q < r->nranks; q++) {
+      const int first = 1 + q * base + (q < rem ? q : rem), w = base + (q < rem ? 1 : 0);
+      const int n = q == r->nranks - 1 ? w + 2 : w;
+      for (int k = 0; k < nrows; k++) {
+        slb_link_begin(r->link);
+        slb_link_recv(r->link, q, all + (size_t)k * total + first, (size_t)n, r->main);
+        slb_link_end(r->link, r->main);
+      }
+    }
+    HIP_OK(hipMemcpy2DAsync(all, sizeof(float) * total, src + (size_t)row0 * s->pitch + lo, sizeof(float) * s->pitch,
+                            sizeof(float) * (hi - lo), nrows, hipMemcpyDeviceToDevice, r->main));
+    HIP_OK(hipStreamSynchronize(r->main));
+    HIP_OK(hipMemcpy(dst, all, sizeof(float) * (size_t)nrows * total, hipMemcpyDeviceToHost));
+    HIP_OK(hipFree(all));
+  } else {
+    for (int k = 0; k < nrows; k++) {
+      slb_link_begin(r->link);
+      slb_link_send(r->link, 0, src + (size_t)(row0 + k) * s->pitch + lo, (size_t)(hi - lo), r->main);
+      slb_link_end(r->link, r->main);
+    }
+    HIP_OK(hipStreamSynchronize(r->main));
+  }
+}
+
+int slb_slabs_ranks_seen(slb_slabs *r) { return r->link ? slb_link_ranks_seen(r->link) : 1; }
+
+void slb_slabs_destroy(slb_slabs *r)
+{
+  if (!r) return;
+  HIP_OK(hipDeviceSynchronize());
+  slb_set_stream(NULL);
+  for (int k = 0; k < r->ring_n; k++) {
+    for (int q = 0; q < AVC_SETS; q++) if (r->ring[k].rows[q]) hipFree(r->ring[k].rows[q]);
+    if (r->ring[k].init) { hipFree(r->ring[k].init); hipFree(r->ring[k].tot); }
+    hipEventDestroy(r->ring[k].done);
+  }
+  free(r->ring);
+  for (int side = 0; side < 2; side++) {
+    hipFree(r->send2[side]); hipFree(r->recv2[side]); hipFree(r->send4[side]); hipFree(r->recv4[side]);
+  }
+  hipFree(r->av_data);
+  hipEventDestroy(r->ev_main); hipEventDestroy(r->ev_side); hipEventDestroy(r->ev_x);
+  hipStreamDestroy(r->main); hipStreamDestroy(r->side); hipStreamDestroy(r->av);
+  slb_solver_destroy(r->s);
+  free(r);
+}
+
+/* ---- the program over slabs: display=4 ---------------------------------------------------
+ * One process per rank, forked before anything has touched a GPU.  Rank q takes device
+ * `device` + q when the machine has that many, and the ranks talk over RCCL; with fewer
+ * devices (a one-GPU box) the ranks share them and talk over sockets -- a rehearsal that
+ * runs the same loop.  SLB_TRANSPORT=fds forces the sockets. */
+static int rank_main(int rank, int nranks, const int *fds)
+{
+  int ndev = 0;
+  HIP_OK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) { fprintf(stderr, "ERROR: no GPU\n"); return EXIT_FAILURE; }
+  const char *tr = getenv("SLB_TRANSPORT");
+  const int use_rccl = nranks > 1 && !(tr && strcmp(tr, "fds") == 0) && ndev >= device + nranks;
+  HIP_OK(hipSetDevice(use_rccl ? device + rank : (device + rank) % ndev));
+
+  float T = host_omega > 0 ? (2 * SLB_PI / host_omega) : 0;
+  t_max = t_start + T;
+  if (rank == 0 && quiet == 0) printf("# t_max = %0.20f\n", t_max);
+  slb_derive_and_load();
+
+  slb_link *link = NULL;
+  if (nranks > 1 && use_rccl) {
+    char id[128];
+    if (rank == 0) {
+      if (slb_link_unique_id(id) != 0) return EXIT_FAILURE;
+      for (int q = 1; q < nranks; q++)
+        if (write(fds[q], id, sizeof(id)) != (ssize_t)sizeof(id)) { perror("ERROR"); return EXIT_FAILURE; }
+    } else if (read(fds[0], id, sizeof(id)) != (ssize_t)sizeof(id)) { perror("ERROR"); return EXIT_FAILURE; }
+    link = slb_link_open_rccl(rank, nranks, id);
+  } else if (nranks > 1) {
+    link = slb_link_open_fds(rank, nranks, fds);
+  }
+  if (nranks > 1 && !link) return EXIT_FAILURE;
+  if (rank == 0 && nranks > 1 && quiet == 0)
+    printf("# %d phi_y slabs, messages over %s (%d ranks seen)\n", nranks, slb_link_transport(link),
+           slb_link_ranks_seen(link));
+
+  slb_slabs *r = slb_slabs_create(rank, nranks, link);
+  if (!r) return EXIT_FAILURE;
+  slb_solver *s = r->s;
+  slb_set_av_mode(SLB_AV_EXACT);
+  slb_slabs_tiptoe(r);
+
+  const int timing = getenv("SLB_TIMING") != NULL;
+  struct timespec w0, w1;
+  if (timing) { HIP_OK(hipDeviceSynchronize()); clock_gettime(CLOCK_MONOTONIC, &w0); }
+  long loop_steps = 0;
+  int progress = 0;
+  float t;
+  for (t = 0; t < t_max; t += host_dt, loop_steps++) {
+    const int k1 = host_E_omega > 0 && t >= t_start;
+    const float t2 = t + host_dt;
+    s->t = t;                              /* the engine forms the cosines from its own clock */
+    if (t2 < t_max) {
+      /* two iterations in one launch: same bits, the lattice in between is never stored
+       * (the rows av() reads of it are) */
+      const int k2 = host_E_omega > 0 && t2 >= t_start;
+      if (k1 || k2) {
+        float *rows[2];
+        slb_slabs_av_rows(r, 2, rows);
+        slb_slabs_double_step(r, rows[0], rows[1]);
+        const float tt[2] = {k1 ? t : t2, t2};
+        slb_slabs_av_submit(r, k1 + k2, tt, k1 ? 0 : 1);
+      } else {
+        slb_slabs_double_step(r, NULL, NULL);
+      }
+      t = t2;
+      loop_steps++;
+      if (rank == 0 && out != stdout && quiet == 0 && (progress += 2) >= 300) {
+        printf("\rt=%0.9f %0.2f%%", t, t / t_max * 100);
+        fflush(stdout);
+        progress = 0;
+      }
+      continue;
+    }
+    slb_slabs_last_step(r);
+    if (k1) slb_slabs_av_submit_current(r, t);
+  }
+  float av6[6] = {0, 0, 0, 0, 0, 0};
+  slb_slabs_av_finish(r, av6);
+  if (timing) {
+    HIP_OK(hipDeviceSynchronize());
+    clock_gettime(CLOCK_MONOTONIC, &w1);
+    const double sec = (double)(w1.tv_sec - w0.tv_sec) + 1e-9 * (double)(w1.tv_nsec - w0.tv_nsec);
+    if (rank == 0)
+      fprintf(stderr, "# time loop: %ld iterations in %.4f s (%.4f ms each)\n", loop_steps, sec,
+              loop_steps ? 1e3 * sec / loop_steps : 0.0);
+  }
+
+  /* the display=4 record from the three rows its sums read, put together on rank 0 */
+  const int total = host_M + 3;
+  float *a01 = rank == 0 ? (float *)malloc(sizeof(float) * 2 * (size_t)total) : NULL;
+  float *b1  = rank == 0 ? (float *)malloc(sizeof(float) * (size_t)total) : NULL;
+  slb_slabs_gather_rows(r, 1 + s->current, 0, 2, a01);
+  slb_slabs_gather_rows(r, 5 + s->current, 1, 1, b1);
+  if (rank == 0) {
+    const float norm = slb_host_norm(a01, host_M, host_dPhi, host_alpha);
+    slb_write_display4(norm, a01, b1, total, av6, T);
+    slb_close_output();
+    free(a01); free(b1);
+  }
+  slb_slabs_destroy(r);
+  slb_link_close(link);
+  return EXIT_SUCCESS;
+}
+
+int slb_slab_main(int nranks)
+{
+  if (display != 4) {
+    fprintf(stderr, "ERROR: with ranks= the program writes display=4 records only.\n");
+    return EXIT_FAILURE;
+  }
+  if (read_from != NULL) {
+    fprintf(stderr, "ERROR: read-from= is not available with ranks=.\n");
+    return EXIT_FAILURE;
+  }
+  if (nranks < 1 || nranks > 64) { fprintf(stderr, "ERROR: Invalid value of ranks= parameter.\n"); return EXIT_FAILURE; }
+  if (nranks == 1) return rank_main(0, 1, NULL);
+  /* a socket for every pair of ranks: start-up data, and the messages themselves when the
+   * ranks share a GPU */
+  int (*pair)[2] = (int (*)[2])malloc(sizeof(int[2]) * (size_t)nranks * nranks);
+  for (int i = 0; i < nranks; i++)
+    for (int j = i + 1; j < nranks; j++)
+      if (socketpair(AF_UNIX, SOCK_STREAM, 0, pair[i * nranks + j]) != 0) { perror("ERROR"); return EXIT_FAILURE; }
+  fflush(NULL);
+  pid_t *pids = (pid_t *)malloc(sizeof(pid_t) * (size_t)nranks);
+  for (int q = 0; q < nranks; q++) {
+    pids[q] = fork();
+    if (pids[q] < 0) { perror("ERROR"); return EXIT_FAILURE; }
+    if (pids[q] == 0) {
+      int *fds = (int *)malloc(sizeof(int) * (size_t)nranks);
+      for (int i = 0; i < nranks; i++)
+        for (int j = i + 1; j < nranks; j++) {
+          int *p = pair[i * nranks + j];
+          if (i == q)      { fds[j] = p[0]; close(p[1]); }
+          else if (j == q) { fds[i] = p[1]; close(p[0]); }
+          else             { close(p[0]); close(p[1]); }
+        }
+      fds[q] = -1;
+      if (q != 0) out = NULL;                 /* rank 0 writes the record */
+      const int rc = rank_main(q, nranks, fds);
+      fflush(NULL);
+      _exit(rc);
+    }
+  }
+  for (int i = 0; i < nranks; i++)
+    for (int j = i + 1; j < nranks; j++) { close(pair[i * nranks + j][0]); close(pair[i * nranks + j][1]); }
+  int worst = EXIT_SUCCESS;
+  for (int q = 0; q < nranks; q++) {
+    int st = 0;
+    if (waitpid(pids[q], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) worst = EXIT_FAILURE;
+  }
+  free(pids); free(pair);
+  return worst;
+}

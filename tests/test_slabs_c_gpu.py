@@ -1,0 +1,125 @@
+"""The slab time loop in C (host/slb_slabs.c, host/slb_link.c).  `boltzmann_solver ranks=N`
+forks N processes; on a one-GPU box they share the GPU and talk over sockets (RCCL refuses
+two ranks on one device), which runs the same launch order, the same halo traffic and the
+same schedule of the av chain as a run over RCCL.  The record must be the single-GPU
+program's, every column to the last digit: same lattices, and av()'s running sums handed
+from slab to slab."""
+import ctypes as C
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BASE = ["display=4", "E_dc=1", "E_omega=0.1", "mu=5", "alpha=1", "PhiYmin=-4", "PhiYmax=4", "quiet=1"]
+
+
+@pytest.mark.parametrize("ranks,extra", [
+    (2, ["omega=100", "B=0.5", "dt=0.001", "n-harmonics=16", "g-grid=4001", "t-max=0.03"]),    # 93 iterations
+    (3, ["omega=100", "B=0.5", "dt=0.001", "n-harmonics=16", "g-grid=4001", "t-max=0.03"]),
+    (5, ["omega=100", "B=0.5", "dt=0.001", "n-harmonics=8", "g-grid=1999", "t-max=0.0305"]),   # averaging starts between the two iterations of a launch
+    (8, ["omega=40", "B=0.8", "dt=0.001", "n-harmonics=24", "g-grid=5003", "t-max=0.02"]),      # 178 iterations, 157 averaged: the chain's ring of batches turns over
+    (3, ["omega=90", "B=0.03", "dt=0.0007", "n-harmonics=5", "g-grid=120001", "t-max=0.01"]),    # slabs wide enough for the parallel form of the sums
+    (4, ["omega=100", "B=0.5", "dt=0.001", "n-harmonics=16", "g-grid=4001", "t-max=0.03", "E_omega=0"]),   # no averaging at all
+])
+def test_program_over_ranks_writes_the_single_gpu_record(ranks, extra, tmp_path, solver_bin):
+    args = BASE + extra
+    one = subprocess.run([solver_bin] + args + ["o=one.txt"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stdout + one.stderr
+    many = subprocess.run([solver_bin] + args + [f"ranks={ranks}", "o=slabs.txt"], cwd=tmp_path, capture_output=True,
+                          text=True, timeout=300)
+    assert many.returncode == 0, many.stdout + many.stderr
+    a, b = (tmp_path / "one.txt").read_text().splitlines(), (tmp_path / "slabs.txt").read_text().splitlines()
+    assert len(a) == 3 and a == b
+
+
+def test_program_over_ranks_refuses_what_it_does_not_do(tmp_path, solver_bin):
+    args = ["E_dc=1", "E_omega=0.1", "mu=5", "alpha=1", "PhiYmin=-4", "PhiYmax=4", "omega=100", "B=0.5",
+            "n-harmonics=8", "g-grid=500", "t-max=0.01", "o=stdout", "ranks=2"]
+    r = subprocess.run([solver_bin, "display=77"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "display=4 records only" in r.stderr
+    r = subprocess.run([solver_bin, "display=4"] + args[:-1] + ["ranks=0"], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=60)
+    assert r.returncode == 1 and "Invalid value of ranks=" in r.stderr
+
+
+def test_single_rank_loop_in_c_matches_the_oracle(slb, oracle):
+    """slb_slabs_* with one rank (no link): double steps with av rows, a last single step,
+    av_finish -- lattices and averaging data bit-identical to the CPU oracle."""
+    import torch
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")
+    N, M = 12, 3001
+    p = oracle.make_params(N=N, M=M, B=0.7, omega=30.0, E_omega=0.2)
+    slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    L = slb.lib()
+    orc = oracle.OracleState(p)
+    r = L.slb_slabs_create(0, 1, None)
+    assert r
+    try:
+        L.slb_slabs_tiptoe(r)
+        s = L.slb_slabs_solver(r).contents
+        av_cpu = np.zeros(6, np.float32)
+        def cpu_av():
+            cur = orc.st.current
+            oracle.lib().orc_av(C.byref(p), orc.array("a", cur), orc.array("b", cur), av_cpu, t_k)
+        for k in range(11):                      # 11 double steps: more than two batches of the chain
+            rows = (C.c_void_p * 2)()
+            L.slb_slabs_av_rows(r, 2, C.byref(rows))
+            tt = (C.c_float * 2)(s.t, np.float32(np.float32(s.t) + np.float32(p.dt)))
+            L.slb_slabs_double_step(r, rows[0], rows[1])
+            L.slb_slabs_av_submit(r, 2, tt, 0)
+            for t_k in tt:
+                t_k = np.float32(t_k)
+                orc.step(1)
+                cpu_av()
+        t_k = np.float32(s.t)
+        L.slb_slabs_last_step(r)
+        L.slb_slabs_av_submit_current(r, t_k)
+        orc.step(1)
+        cpu_av()
+        av6 = (C.c_float * 6)()
+        L.slb_slabs_av_finish(r, C.byref(av6))
+        torch.cuda.synchronize()
+        assert np.array_equal(np.array(av6, dtype=np.float32).view(np.uint32), av_cpu.view(np.uint32))
+        assert np.float32(s.t) == np.float32(orc.st.t)
+        total = np.empty((N + 1, M + 3), np.float32)
+        for which, arr, idx in (("a", 1 + s.current, orc.st.current), ("b", 5 + s.current, orc.st.current),
+                                ("a", 1 + s.current_hs, orc.st.current_hs), ("b", 5 + s.current_hs, orc.st.current_hs)):
+            L.slb_slabs_gather_rows(r, arr, 0, N + 1, total.ctypes.data)
+            assert np.array_equal(total.view(np.uint32), orc.array(which, idx).view(np.uint32)), which
+    finally:
+        L.slb_slabs_destroy(r)
+        orc.close()
+
+
+def test_rccl_link_moves_a_message_on_this_gpu(slb):
+    """The RCCL transport itself, as far as one GPU goes: librccl is found and opened at run
+    time, a communicator of one rank comes up from an identifier made here, and a grouped
+    ncclSend/ncclRecv pair addressed to the rank itself moves a device buffer on a stream."""
+    import torch
+    torch.cuda.set_device(0)
+    L = slb.lib()
+    ident = C.create_string_buffer(128)
+    assert L.slb_link_unique_id(ident) == 0
+    link = L.slb_link_open_rccl(0, 1, ident.raw)
+    assert link
+    try:
+        assert L.slb_link_ranks_seen(link) == 1 and L.slb_link_transport(link) == b"rccl"
+        st = torch.cuda.Stream()
+        src = torch.arange(5000, dtype=torch.float32, device="cuda") * 0.5
+        dst = torch.zeros_like(src)
+        st.wait_stream(torch.cuda.current_stream())
+        for n in (5000, 7):
+            L.slb_link_begin(link)
+            L.slb_link_send(link, 0, src.data_ptr(), n, st.cuda_stream)
+            L.slb_link_recv(link, 0, dst.data_ptr(), n, st.cuda_stream)
+            L.slb_link_end(link, st.cuda_stream)
+            st.synchronize()
+            assert torch.equal(dst[:n], src[:n])
+            dst.zero_()
+            torch.cuda.synchronize()
+    finally:
+        L.slb_link_close(link)
