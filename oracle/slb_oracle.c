@@ -458,26 +458,39 @@ int orc_solver_run(orc_state *s, int display, FILE *out, FILE *log, long max_ste
 }
 
 /* read-from=stdin: one of E_dc, E_omega, omega, mu, alpha, B is replaced and the run goes
- * on from the present state for `timeout` more time units plus one period
- * (reference: src/boltzmann_solver.c:384-393, the host in which the new value reaches the
- * sweeps; the derived constants are refreshed as well, so a new B really is the new B).
- * t_max is formed with the OLD period, as there.  Returns 0, or -1 for an unknown name. */
+ * on from the present state for `timeout` more time units plus one period.  The two
+ * reference programs disagree on what "replaced" means, so there are three forms, chosen by
+ * the environment variable SLB_REPARAM (the same switch the GPU program reads):
+ *   cuda  (default) the CUDA host, reference src/boltzmann_solver.c:384-393: the new value
+ *         reaches the sweeps through load_data(), but the derived constant bdt = B dt / (4 dPhi)
+ *         is NOT formed again (host_bdt is only computed at start-up, :113), so a new B acts
+ *         through the field term only;
+ *   cpu   the CPU solver, reference src/boltzmann_c_solver.c:270-280: scan_for_new_parameters()
+ *         sets the host_* copies and nobody reads them again (no load_data()), so the new
+ *         value is ignored; only the averaging window moves;
+ *   fixed what the feature is for: the new value and every constant derived from it.
+ * In all three t_max is formed with the OLD period, the averaging data are cleared, and a0
+ * (which depends on mu and alpha) stays as it was built at start-up.
+ * Returns 0, or -1 for an unknown name. */
 int orc_solver_continue(orc_state *s, const char *name, float value, float timeout)
 {
   orc_params *p = &s->p;
+  const char *mode = getenv("SLB_REPARAM");
+  const int cpu = mode && !strcmp(mode, "cpu"), fixed = mode && !strcmp(mode, "fixed");
   int known = 1;
-  if      (!strcmp(name, "E_dc"))    p->E_dc = value;
-  else if (!strcmp(name, "E_omega")) p->E_omega = value;
-  else if (!strcmp(name, "omega"))   p->omega = value;
-  else if (!strcmp(name, "mu"))      p->mu = value;
-  else if (!strcmp(name, "alpha"))   p->alpha = value;
-  else if (!strcmp(name, "B"))       p->B = value;
+  float ignored;
+  if      (!strcmp(name, "E_dc"))    *(cpu ? &ignored : &p->E_dc) = value;
+  else if (!strcmp(name, "E_omega")) *(cpu ? &ignored : &p->E_omega) = value;
+  else if (!strcmp(name, "omega"))   *(cpu ? &ignored : &p->omega) = value;
+  else if (!strcmp(name, "mu"))      *(cpu ? &ignored : &p->mu) = value;
+  else if (!strcmp(name, "alpha"))   *(cpu ? &ignored : &p->alpha) = value;
+  else if (!strcmp(name, "B"))       *(cpu ? &ignored : &p->B) = value;
   else known = 0;
   p->t_start = s->t + timeout;
   s->t_max = p->t_start + s->T;
   s->t0 = s->t + p->dt;
   s->T = p->omega > 0 ? (2 * ORC_PI / p->omega) : 0;
-  orc_derive(p);
+  if (fixed) orc_derive(p);
   memset(s->av_data, 0, sizeof(s->av_data));
   return known ? 0 : -1;
 }

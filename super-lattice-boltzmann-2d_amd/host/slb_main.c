@@ -554,16 +554,27 @@ int slb_main(int argc, char **argv)
     if (read_from == NULL) break;
 
     /* new parameter from stdin, continue from the present state
-     * (reference: src/boltzmann_solver.c:384-393) */
+     * (reference: src/boltzmann_solver.c:384-393).  What the new value does is the
+     * reference host's by default -- load_data() re-reads the host_* values, but bdt =
+     * B dt / (4 dPhi) is only ever formed at start-up (:113), so a new B acts through the
+     * field term alone.  SLB_REPARAM=fixed forms the derived constants again;
+     * SLB_REPARAM=cpu does what the reference's CPU solver does
+     * (src/boltzmann_c_solver.c:270-280: nothing reads the new value, only the averaging
+     * window moves). */
+    const char *mode = getenv("SLB_REPARAM");
+    const float keep[6] = {host_E_dc, host_E_omega, host_omega, host_mu, host_alpha, host_B};
     const float timeout = scan_for_new_parameters();
     if (timeout < -900) break;
+    if (mode != NULL && strcmp(mode, "cpu") == 0) {
+      host_E_dc = keep[0]; host_E_omega = keep[1]; host_omega = keep[2];
+      host_mu = keep[3]; host_alpha = keep[4]; host_B = keep[5];
+    }
     t_start = t + timeout;
     t_max = t_start + T;
     t0 = t + host_dt;
     T = host_omega > 0 ? (2 * SLB_PI / host_omega) : 0;
-    /* B enters the sweeps through bdt, so the derived constants are refreshed
-     * as well (the reference re-uploads a stale bdt here) */
-    slb_derive_and_load();
+    if (mode != NULL && strcmp(mode, "fixed") == 0) slb_derive_and_load();
+    else load_data();
     HIP_OK(hipMemset(s->av_data, 0, 6 * sizeof(float)));
     if (quiet == 0) printf("# t_max = %0.20f\n", t_max);
   }

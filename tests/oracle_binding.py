@@ -120,7 +120,8 @@ def frame_values(p, a, b, phi_x):
     return out
 
 
-def run_cli(args, threads=8, timeout=600, cwd=None, stdin_text=None):
+def run_cli(args, threads=8, timeout=600, cwd=None, stdin_text=None, env=None):
     lib()
     return subprocess.run([CLI] + list(args) + [f"threads={threads}"], check=True, timeout=timeout,
-                          capture_output=True, text=True, cwd=cwd, input=stdin_text)
+                          capture_output=True, text=True, cwd=cwd, input=stdin_text,
+                          env=None if env is None else {**os.environ, **env})

@@ -22,7 +22,7 @@ STEPS = 9
 def _worker(rank, world, port, outdir, mode):
     import faulthandler
     import torch
-    faulthandler.dump_traceback_later(300, exit=True)     # a stuck rank says where, then ends
+    faulthandler.dump_traceback_later(90, exit=True)      # a stuck rank says where, then ends
     torch.cuda.set_device(0)
     torch.zeros(1, device="cuda")
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -100,7 +100,7 @@ def test_slabs_on_one_gpu(world, mode, tmp_path):
 def _av_worker(rank, world, port, outdir, phys):
     import faulthandler
     import torch
-    faulthandler.dump_traceback_later(300, exit=True)
+    faulthandler.dump_traceback_later(90, exit=True)
     torch.cuda.set_device(0)
     torch.zeros(1, device="cuda")
     if world > 1:

@@ -213,3 +213,27 @@ def test_oracle_reproduces_what_was_observed_on_the_reference_at_config2(oracle,
     obs = json.load(open(os.path.join(GOLDEN, "config2_display77_reference_observations.json")))
     oracle.run_cli(obs["args"].split() + ["o=out.txt"], cwd=tmp_path, threads=8)
     _check_config2_observations((tmp_path / "out.txt").read_text())
+
+
+def test_reparameterisation_modes_of_the_oracle(oracle, tmp_path):
+    """read-from=stdin in the three readings of the reference (SLB_REPARAM): the CPU solver's
+    (reference src/boltzmann_c_solver.c:270-280, new values are never read: the run equals one
+    whose records repeat the old values), the CUDA host's (src/boltzmann_solver.c:384-393, the
+    default: a new B acts without its derived constant bdt) and the repaired one (differs from
+    the CUDA host's only after the record that changes B)."""
+    args = ["display=4", "E_dc=1", "E_omega=0.1", "omega=100", "mu=5", "alpha=1", "PhiYmin=-4", "PhiYmax=4",
+            "B=0.5", "n-harmonics=6", "g-grid=121", "t-max=0.02", "dt=0.001", "read-from=stdin", "o=out.txt"]
+    new = "E_dc 1.5 0.02\nB 0.4 0.013\nexit\n"
+    same = "E_dc 1 0.02\nB 0.5 0.013\nexit\n"
+
+    def run(name, text, mode):
+        d = tmp_path / name
+        d.mkdir()
+        oracle.run_cli(args, cwd=d, stdin_text=text, threads=2, env={"SLB_REPARAM": mode} if mode else None)
+        return (d / "out.txt").read_text().splitlines()
+
+    cpu, unchanged = run("cpu", new, "cpu"), run("same", same, None)
+    cuda, default, fixed = run("cuda", new, "cuda"), run("default", new, None), run("fixed", new, "fixed")
+    assert len(cpu) == 9 and cpu == unchanged
+    assert cuda == default and cuda != cpu
+    assert fixed[:6] == cuda[:6] and fixed[6] == cuda[6] and fixed[8] != cuda[8]

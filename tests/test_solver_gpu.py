@@ -52,7 +52,7 @@ def _run_both(solver_bin, oracle, tmp_path, args, extra_files=(), stdin_text=Non
     g = subprocess.run([solver_bin] + args + ["o=out.txt"], cwd=gdir, capture_output=True, text=True, timeout=600,
                        input=stdin_text, env=None if env is None else {**os.environ, **env})
     assert g.returncode == 0, g.stdout + g.stderr
-    o = oracle.run_cli(args + ["o=out.txt"], cwd=odir, stdin_text=stdin_text)
+    o = oracle.run_cli(args + ["o=out.txt"], cwd=odir, stdin_text=stdin_text, env=env)
     return gdir, odir, g, o
 
 
@@ -127,6 +127,25 @@ def test_program_display77_identical(solver_bin, oracle, tmp_path):
     assert pick(g.stdout) == pick(o.stdout)
 
 
+def test_program_display77_config2_full_size_identical(solver_bin, oracle, tmp_path):
+    """BASELINE config 2 at its full size (display=77, n-harmonics=64, g-grid=262144, B=0.015,
+    113 iterations, 11 records; reference: src/boltzmann_c_solver.c:178-186, 298-331): all 22
+    lines of the trace and the norm log equal the CPU oracle's, which runs the same lattice on
+    the host's cores."""
+    args = ["display=77", "omega=100", "B=0.015", "n-harmonics=64", "g-grid=262144", "t-max=0.05"] + COMMON
+    gdir, odir = tmp_path / "gpu", tmp_path / "orc"
+    gdir.mkdir(), odir.mkdir()
+    g = subprocess.run([solver_bin] + args + ["o=out.txt"], cwd=gdir, capture_output=True, text=True, timeout=600)
+    assert g.returncode == 0, g.stdout + g.stderr
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or 16
+    o = oracle.run_cli(args + ["o=out.txt"], cwd=odir, threads=threads, timeout=900)
+    got, exp = (gdir / "out.txt").read_text(), (odir / "out.txt").read_text()
+    assert len(exp.splitlines()) == 22
+    assert got == exp
+    pick = lambda s: [l for l in s.splitlines() if l.startswith("# t=")]
+    assert pick(g.stdout) == pick(o.stdout) and len(pick(o.stdout)) == 11
+
+
 def test_program_display8_identical(solver_bin, oracle, tmp_path):
     args = ["display=8", "omega=100", "B=0.5", "n-harmonics=8", "g-grid=61", "t-max=0.01"] + COMMON
     gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
@@ -135,21 +154,34 @@ def test_program_display8_identical(solver_bin, oracle, tmp_path):
     assert got == exp
 
 
-@pytest.mark.parametrize("form", ["double", "fused", "sweeps"])
-def test_program_read_from_stdin_goes_on_with_new_parameters(solver_bin, oracle, tmp_path, form):
+@pytest.mark.parametrize("form,mode", [("double", None), ("fused", None), ("sweeps", None),
+                                       ("double", "fixed"), ("double", "cpu"), ("sweeps", "cuda")])
+def test_program_read_from_stdin_goes_on_with_new_parameters(solver_bin, oracle, tmp_path, form, mode):
     """read-from=stdin: after each display=4 record one parameter is replaced and the run
-    continues from the present state (new E_dc, new B with its derived constant, new omega
-    with the old period still in t_max); every record equals the oracle's."""
+    continues from the present state (new E_dc, new B, new omega with the old period still in
+    t_max); every record equals the oracle's, in each of the three readings of "replaced"
+    (SLB_REPARAM: the reference CUDA host's -- the default: a new B without its derived
+    constant --, the reference CPU solver's -- the value is ignored --, and the repaired one).
+    No reference output pins this path (the reference holds none): parity unpinned."""
     args = ["display=4", "omega=100", "B=0.5", "n-harmonics=8", "g-grid=253", "t-max=0.02",
             "read-from=stdin"] + COMMON
     records = "E_dc 1.5 0.02\nB 0.4 0.013\nomega 50 0.01\nbogus 1 0.005\nexit\n"
-    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args, stdin_text=records,
-                                 env=None if form == "double" else {"SLB_FORM": form})
+    env = {}
+    if form != "double":
+        env["SLB_FORM"] = form
+    if mode is not None:
+        env["SLB_REPARAM"] = mode
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args, stdin_text=records, env=env or None)
     got, exp = (gdir / "out.txt").read_text(), (odir / "out.txt").read_text()
     assert len(exp.splitlines()) == 15            # five records of three lines
     assert got == exp
     pick = lambda s: [l for l in s.splitlines() if l.startswith("# t_max")]
     assert pick(g.stdout) == pick(o.stdout) and len(pick(o.stdout)) == 5
+    rec = [l.split() for l in exp.splitlines() if not l.startswith("#")]
+    if mode == "cpu":                             # the new values never show, not even in the record
+        assert all(r[0] == rec[0][0] and r[2] == rec[0][2] for r in rec)
+    else:
+        assert float(rec[1][0]) == 1.5 and float(rec[3][2]) == 50.0
 
 
 def test_program_display7_movie_frames_identical(solver_bin, oracle, tmp_path):
