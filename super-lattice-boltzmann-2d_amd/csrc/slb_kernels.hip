@@ -1592,11 +1592,11 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 // lattices (a thousand workgroups across already) take the chunk length measured fastest
 // at full size, narrower ones are cut into shorter chunks -- down to 4 rows -- until about
 // a thousand workgroups exist, because there the row loop is all the launch costs.
-int auto_chunk(int N, int cols, int cols_per_wave, int block, int full_size_chunk)
+int auto_chunk(int N, int cols, int cols_per_wave, int block, int full_size_chunk, int target_wgs = 1024)
 {
   const int waves = (cols + cols_per_wave - 1) / cols_per_wave;
   const int wgs_x = (waves + block / 64 - 1) / (block / 64);
-  int chunks = (1024 + wgs_x - 1) / wgs_x;
+  int chunks = (target_wgs + wgs_x - 1) / wgs_x;
   const int most = N / 4 > 0 ? N / 4 : 1;
   if (chunks > most) chunks = most;
   int nc = (N + chunks - 1) / chunks;
@@ -1941,7 +1941,9 @@ int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
   // likewise).  Lattices narrower than about a thousand workgroups get shorter chunks.
   int cap = 32;
   if (s.N >= 128) cap = (7 * s.N + 15) / 16;
-  const int tail_chunk = auto_chunk(s.N, hi - lo + 1, 248, block, cap);
+  // (two rounds of workgroups rather than one: at n-harmonics 64, g-grid 2^18 chunks of 11-12
+  // rows take 0.176-0.178 ms per launch, 16 rows 0.183, 22 rows 0.191, 32 rows 0.204)
+  const int tail_chunk = auto_chunk(s.N, hi - lo + 1, 248, block, cap, 1536);
   // tuning variant 26: every strip group cut into chunks, as for a narrow lattice
   int n_chunk = g_n_chunk > 0 ? g_n_chunk : (g_variant == 26 || s.N < 64 ? tail_chunk : 0);
   if (rows_first) return launch_fused2<3, false, true>(s, block, n_chunk, tail_chunk);
