@@ -225,7 +225,8 @@ void       *slb_slabs_main_stream(slb_slabs *r);
 int         slb_slabs_ranks_seen(slb_slabs *r);
 void        slb_slabs_tiptoe(slb_slabs *r);
 void        slb_slabs_double_step(slb_slabs *r, float *rows_first, float *rows_second);
-void        slb_slabs_last_step(slb_slabs *r);
+void        slb_slabs_step(slb_slabs *r);          /* one iteration, ghost columns refreshed */
+void        slb_slabs_last_step(slb_slabs *r);     /* the last iteration of a run: nothing travels */
 void        slb_slabs_join(slb_slabs *r);
 /* av() over slabs, bit-identical to the single-GPU av(): buffers for the next step's rows,
  * the step's loop times once it has been queued, and the end of the chain (av6 on rank 0) */
@@ -233,9 +234,10 @@ void        slb_slabs_av_rows(slb_slabs *r, int n, float *rows[2]);
 void        slb_slabs_av_submit(slb_slabs *r, int n, const float *t, int skip);
 void        slb_slabs_av_submit_current(slb_slabs *r, float t);
 void        slb_slabs_av_finish(slb_slabs *r, float av6[6]);
+void        slb_slabs_av_set(slb_slabs *r, const float av6[6]);
 float      *slb_slabs_av_data(slb_slabs *r);
 void        slb_slabs_gather_rows(slb_slabs *r, int arr, int row0, int nrows, float *dst);
-/* the display=4 program over `nranks` processes, forked here (nothing may have touched a
+/* the display=4 / display=77 program over `nranks` processes, forked here (nothing may have touched a
  * GPU yet); parse_cmd() has run */
 int         slb_slab_main(int nranks);
 

@@ -18,6 +18,12 @@
 #include "slb_host.h"
 
 #define HIP_OK(call) HandleError((int)(call), __FILE__, __LINE__)
+/* rows of a device array for the host-side sums; a refused request ends the run */
+#define GET_ROWS(s, arr, row0, nrows, dst) \
+  do { if (slb_solver_get_rows((s), (arr), (row0), (nrows), (dst)) != 0) { \
+         fprintf(stderr, "ERROR: rows %d..%d of array %d do not exist (n-harmonics=%d)\n", \
+                 (row0), (row0) + (nrows) - 1, (arr), host_N); \
+         exit(EXIT_FAILURE); } } while (0)
 
 static const char *HDR4 =
   "#E_{dc}                \\tilde{E}_{\\omega}     \\tilde{\\omega}         mu                     "
@@ -370,7 +376,13 @@ int slb_main(int argc, char **argv)
   parse_cmd(argc, argv);
   /* ranks=N: N processes, one per GPU, each with a phi_y slab of the lattice (forked
    * before anything here has touched a GPU) */
-  if (ranks != 1) return slb_slab_main(ranks);
+  if (ranks != 1 || getenv("SLB_FORCE_SLABS") != NULL) return slb_slab_main(ranks);   /* (the variable: the slab loop with one rank, for tests) */
+  if (display == 77 && host_N < 2) {
+    /* its sums read rows 0-2 of a and 1-2 of b (reference: src/boltzmann_c_solver.c:303-310);
+     * the reference reads past the end of its arrays here */
+    fprintf(stderr, "ERROR: display=77 needs n-harmonics >= 2.\n");
+    return EXIT_FAILURE;
+  }
   HIP_OK(hipSetDevice(device));
 
   float T = host_omega > 0 ? (2 * SLB_PI / host_omega) : 0;   /* period of the a/c field */
@@ -466,8 +478,8 @@ int slb_main(int argc, char **argv)
       if (host_E_omega > 0 && display == 77 && frame_time >= 0.01) {
         av_ring_drain(s);
         av(0, s->a[s->next], s->b[s->next], s->av_data, t);
-        slb_solver_get_rows(s, 1 + s->current, 0, 3, a_rows);
-        slb_solver_get_rows(s, 5 + s->current, 1, 2, b_rows);
+        GET_ROWS(s, 1 + s->current, 0, 3, a_rows);
+        GET_ROWS(s, 5 + s->current, 1, 2, b_rows);
         HIP_OK(hipMemcpy(av6, s->av_data, sizeof(av6), hipMemcpyDeviceToHost));
         const float norm = slb_host_norm(a_rows, host_M, host_dPhi, host_alpha);
         slb_write_display77(norm, a_rows, b_rows, pitch, av6, t);
@@ -485,7 +497,7 @@ int slb_main(int argc, char **argv)
         float tT = t / T;
         float tT_reminder = tT - ((int)tT);
         if (tT_reminder < last_tT_reminder) {
-          slb_solver_get_rows(s, 1 + s->current, 0, 1, a_rows);
+          GET_ROWS(s, 1 + s->current, 0, 1, a_rows);
           sprintf(file_name, "strobe%08d.data", frame_number++);
           FILE *f = fopen(file_name, "w");
           if (!f) { perror("ERROR"); return EXIT_FAILURE; }
@@ -498,7 +510,7 @@ int slb_main(int argc, char **argv)
         last_tT_reminder = tT_reminder;
       }
       if (display == 7 && frame_time >= 0.01 && t > frame_start) {      /* a movie frame */
-        slb_solver_get_rows(s, 1 + s->current, 0, 2, a_rows);
+        GET_ROWS(s, 1 + s->current, 0, 2, a_rows);
         sprintf(file_name, "frame%08d.data", frame_number++);
         FILE *f = fopen(file_name, "w");
         if (!f) { perror("ERROR"); return EXIT_FAILURE; }
@@ -527,8 +539,8 @@ int slb_main(int argc, char **argv)
       fprintf(stderr, "# time loop: %ld iterations in %.4f s (%.4f ms each)\n", loop_steps, sec,
               loop_steps ? 1e3 * sec / loop_steps : 0.0);
     }
-    slb_solver_get_rows(s, 1 + s->current, 0, 2, a_rows);
-    slb_solver_get_rows(s, 5 + s->current, 1, 1, b_rows);
+    GET_ROWS(s, 1 + s->current, 0, 2, a_rows);
+    GET_ROWS(s, 5 + s->current, 1, 1, b_rows);
     HIP_OK(hipMemcpy(av6, s->av_data, sizeof(av6), hipMemcpyDeviceToHost));
     const float norm = slb_host_norm(a_rows, host_M, host_dPhi, host_alpha);
 

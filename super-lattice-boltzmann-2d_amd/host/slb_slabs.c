@@ -209,7 +209,11 @@ void slb_slabs_double_step(slb_slabs *r, float *rows_first, float *rows_second)
     return;
   }
   on_stream(r->main);
-  slb_solver_prepare_double_step(s);                  /* spare arrays, if stale, on the main stream */
+  /* spare arrays, if stale (first use, or a single step since): copied on the main stream,
+   * after whatever the side stream still has to put into the lattices they are copies of */
+  if (r->side_busy && (!s->spare_a || s->spare_of != s->current || s->spare_of_hs != s->current_hs))
+    HIP_OK(hipStreamWaitEvent(r->main, r->ev_side, 0));
+  slb_solver_prepare_double_step(s);
   /* halo chain: reads what the last interior launch wrote, writes the spare arrays' edge
    * and ghost columns (which that launch read) */
   if (!r->side_busy) HIP_OK(hipEventRecord(r->ev_main, r->main));
@@ -252,6 +256,33 @@ void slb_slabs_last_step(slb_slabs *r)
   slb_slabs_join(r);
   slb_solver_step_fused(r->s);
   HIP_OK(hipEventRecord(r->ev_main, r->main));
+}
+
+/* One loop iteration as one fused launch, after which any step may follow: the slab forms
+ * both sweeps for all its columns (as above), then the ghost columns of both new lattices
+ * come from the neighbours -- 3 columns of the main lattice, 4 of the half-step one, the
+ * depth a double step reads. */
+void slb_slabs_step(slb_slabs *r)
+{
+  slb_solver *s = r->s;
+  slb_slabs_join(r);
+  slb_solver_step_fused(s);
+  HIP_OK(hipEventRecord(r->ev_main, r->main));
+  HIP_OK(hipStreamWaitEvent(r->side, r->ev_main, 0));
+  on_stream(r->side);
+  static const int which[2] = {3, 0}, ncols[2] = {3, 4};    /* current main lattice, current half-step lattice */
+  for (int k = 0; k < 2; k++) {
+    for (int side = 0; side < 2; side++)
+      if ((side == 0 ? r->left : r->right) >= 0)
+        check(slb_solver_halo_pack(s, which[k], side, ncols[k], r->send4[side]), "halo pack");
+    exchange(r, r->send4, r->recv4, 2 * (size_t)ncols[k] * (size_t)(s->N + 1));
+    for (int side = 0; side < 2; side++)
+      if ((side == 0 ? r->left : r->right) >= 0)
+        check(slb_solver_halo_unpack(s, which[k], side, ncols[k], r->recv4[side]), "halo unpack");
+  }
+  HIP_OK(hipEventRecord(r->ev_side, r->side));
+  r->side_busy = 1;
+  on_stream(r->main);
 }
 
 /* ---- av chain --------------------------------------------------------------------------- */
@@ -383,6 +414,22 @@ void slb_slabs_av_finish(slb_slabs *r, float av6[6])
   if (r->rank == 0) HIP_OK(hipMemcpy(av6, r->av_data, 6 * sizeof(float), hipMemcpyDeviceToHost));
 }
 
+/* The averaging data as rank 0 has them on the host become the chain's (they live on the
+ * last rank): display=77 rescales them in place at every record
+ * (reference: src/boltzmann_c_solver.c:319-325). */
+void slb_slabs_av_set(slb_slabs *r, const float av6[6])
+{
+  HIP_OK(hipStreamSynchronize(r->av));
+  if (r->rank == 0) HIP_OK(hipMemcpy(r->av_data, av6, 6 * sizeof(float), hipMemcpyHostToDevice));
+  if (r->nranks > 1) {
+    slb_link_begin(r->link);
+    if (r->rank == 0) slb_link_send(r->link, r->nranks - 1, r->av_data, 6, r->av);
+    if (r->rank == r->nranks - 1) slb_link_recv(r->link, 0, r->av_data, 6, r->av);
+    slb_link_end(r->link, r->av);
+    HIP_OK(hipStreamSynchronize(r->av));
+  }
+}
+
 /* Rows [row0, row0+nrows) of device array `arr` (numbering of slb_solver_get_rows) over
  * all slabs: on rank 0, dst receives nrows x (M+3) floats (global columns 0..M+2); other
  * ranks send their columns and leave dst alone. */
@@ -454,11 +501,19 @@ void slb_slabs_destroy(slb_slabs *r)
   free(r);
 }
 
-/* ---- the program over slabs: display=4 ---------------------------------------------------
+/* ---- the program over slabs: display=4 and display=77 ------------------------------------
  * One process per rank, forked before anything has touched a GPU.  Rank q takes device
  * `device` + q when the machine has that many, and the ranks talk over RCCL; with fewer
  * devices (a one-GPU box) the ranks share them and talk over sockets -- a rehearsal that
  * runs the same loop.  SLB_TRANSPORT=fds forces the sockets. */
+/* What follows the step taken at loop time t with this frame_time: 0 nothing, 1 only av(),
+ * 2 a display=77 record.  Two steps of kind 0 or 1 may share a launch. */
+static int step_kind(float t, float frame_time)
+{
+  if (display == 77) return host_E_omega > 0 && frame_time >= 0.01 ? 2 : 0;
+  return host_E_omega > 0 && t >= t_start ? 1 : 0;
+}
+
 static int rank_main(int rank, int nranks, const int *fds)
 {
   int ndev = 0;
@@ -501,15 +556,18 @@ static int rank_main(int rank, int nranks, const int *fds)
   if (timing) { HIP_OK(hipDeviceSynchronize()); clock_gettime(CLOCK_MONOTONIC, &w0); }
   long loop_steps = 0;
   int progress = 0;
-  float t;
+  float t, frame_time = 0;
+  const int total = host_M + 3;
+  float *a012 = rank == 0 ? (float *)malloc(sizeof(float) * 3 * (size_t)total) : NULL;
+  float *b12  = rank == 0 ? (float *)malloc(sizeof(float) * 2 * (size_t)total) : NULL;
   for (t = 0; t < t_max; t += host_dt, loop_steps++) {
-    const int k1 = host_E_omega > 0 && t >= t_start;
-    const float t2 = t + host_dt;
+    const int k1 = step_kind(t, frame_time);
+    const float t2 = t + host_dt, ft2 = frame_time + host_dt;
+    const int k2 = step_kind(t2, ft2);
     s->t = t;                              /* the engine forms the cosines from its own clock */
-    if (t2 < t_max) {
+    if (t2 < t_max && k1 < 2 && k2 < 2) {
       /* two iterations in one launch: same bits, the lattice in between is never stored
        * (the rows av() reads of it are) */
-      const int k2 = host_E_omega > 0 && t2 >= t_start;
       if (k1 || k2) {
         float *rows[2];
         slb_slabs_av_rows(r, 2, rows);
@@ -521,6 +579,7 @@ static int rank_main(int rank, int nranks, const int *fds)
       }
       t = t2;
       loop_steps++;
+      frame_time = ft2 + host_dt;
       if (rank == 0 && out != stdout && quiet == 0 && (progress += 2) >= 300) {
         printf("\rt=%0.9f %0.2f%%", t, t / t_max * 100);
         fflush(stdout);
@@ -528,8 +587,25 @@ static int rank_main(int rank, int nranks, const int *fds)
       }
       continue;
     }
-    slb_slabs_last_step(r);
-    if (k1) slb_slabs_av_submit_current(r, t);
+    if (t2 < t_max) slb_slabs_step(r); else slb_slabs_last_step(r);
+    if (k1 == 2) {
+      /* a display=77 record: av() of the lattice this step wrote, the sums from the one
+       * before it (reference: src/boltzmann_c_solver.c:180-187, 298-331) */
+      float av6[6] = {0, 0, 0, 0, 0, 0};
+      slb_slabs_av_submit_current(r, t);
+      slb_slabs_av_finish(r, av6);
+      slb_slabs_gather_rows(r, 1 + s->next, 0, 3, a012);     /* after the swap `next` is the old lattice */
+      slb_slabs_gather_rows(r, 5 + s->next, 1, 2, b12);
+      if (rank == 0) {
+        const float norm = slb_host_norm(a012, host_M, host_dPhi, host_alpha);
+        slb_write_display77(norm, a012, b12, total, av6, t);
+      }
+      slb_slabs_av_set(r, av6);            /* the CPU solver rescales its averaging data in place */
+      frame_time = 0;
+    } else if (k1 == 1) {
+      slb_slabs_av_submit_current(r, t);
+    }
+    frame_time += host_dt;
   }
   float av6[6] = {0, 0, 0, 0, 0, 0};
   slb_slabs_av_finish(r, av6);
@@ -542,18 +618,17 @@ static int rank_main(int rank, int nranks, const int *fds)
               loop_steps ? 1e3 * sec / loop_steps : 0.0);
   }
 
-  /* the display=4 record from the three rows its sums read, put together on rank 0 */
-  const int total = host_M + 3;
-  float *a01 = rank == 0 ? (float *)malloc(sizeof(float) * 2 * (size_t)total) : NULL;
-  float *b1  = rank == 0 ? (float *)malloc(sizeof(float) * (size_t)total) : NULL;
-  slb_slabs_gather_rows(r, 1 + s->current, 0, 2, a01);
-  slb_slabs_gather_rows(r, 5 + s->current, 1, 1, b1);
-  if (rank == 0) {
-    const float norm = slb_host_norm(a01, host_M, host_dPhi, host_alpha);
-    slb_write_display4(norm, a01, b1, total, av6, T);
-    slb_close_output();
-    free(a01); free(b1);
+  if (display == 4) {
+    /* the display=4 record from the three rows its sums read, put together on rank 0 */
+    slb_slabs_gather_rows(r, 1 + s->current, 0, 2, a012);
+    slb_slabs_gather_rows(r, 5 + s->current, 1, 1, b12);
+    if (rank == 0) {
+      const float norm = slb_host_norm(a012, host_M, host_dPhi, host_alpha);
+      slb_write_display4(norm, a012, b12, total, av6, T);
+    }
   }
+  if (rank == 0) slb_close_output();
+  free(a012); free(b12);
   slb_slabs_destroy(r);
   slb_link_close(link);
   return EXIT_SUCCESS;
@@ -561,10 +636,11 @@ static int rank_main(int rank, int nranks, const int *fds)
 
 int slb_slab_main(int nranks)
 {
-  if (display != 4) {
-    fprintf(stderr, "ERROR: with ranks= the program writes display=4 records only.\n");
+  if (display != 4 && display != 77) {
+    fprintf(stderr, "ERROR: with ranks= the program writes display=4 records and display=77 traces only.\n");
     return EXIT_FAILURE;
   }
+  if (display == 77 && host_N < 2) { fprintf(stderr, "ERROR: display=77 needs n-harmonics >= 2.\n"); return EXIT_FAILURE; }
   if (read_from != NULL) {
     fprintf(stderr, "ERROR: read-from= is not available with ranks=.\n");
     return EXIT_FAILURE;

@@ -139,3 +139,9 @@ def test_argument_errors_are_reported_without_a_launch(slb, capfd):
     assert L.slb_halo_unpack(ok[0], ok[1], 64, 0, 1, 1, ok[2]) == -1                  # no rows
     err = capfd.readouterr().err
     assert "bad geometry" in err and "16-byte aligned" in err and "block must be" in err
+
+
+def test_display77_needs_the_rows_its_sums_read(solver_bin, tmp_path):
+    r = _run(solver_bin, ["display=77"] + [a for a in ARGS[1:] if not a.startswith("n-harmonics")] +
+             ["n-harmonics=1", "o=stdout"], cwd=tmp_path)
+    assert r.returncode == 1 and "display=77 needs n-harmonics >= 2" in r.stderr

@@ -5,6 +5,7 @@ same schedule of the av chain as a run over RCCL.  The record must be the single
 program's, every column to the last digit: same lattices, and av()'s running sums handed
 from slab to slab."""
 import ctypes as C
+import os
 import subprocess
 
 import numpy as np
@@ -34,11 +35,30 @@ def test_program_over_ranks_writes_the_single_gpu_record(ranks, extra, tmp_path,
     assert len(a) == 3 and a == b
 
 
+@pytest.mark.parametrize("ranks,grid", [(1, "4001"), (3, "4001"), (4, "70001")])
+def test_program_over_ranks_writes_the_single_gpu_trace(ranks, grid, tmp_path, solver_bin):
+    """display=77 over ranks: every record of the trace (sums over the CPU solver's flat index,
+    averaging data rescaled in place at each record and handed back to the chain) and the norm
+    log equal the single-GPU program's; single steps with a ghost refresh alternate with
+    double steps here."""
+    args = ["display=77", "E_dc=1", "E_omega=0.1", "omega=100", "mu=5", "alpha=1", "B=0.05", "PhiYmin=-4",
+            "PhiYmax=4", "dt=0.001", "n-harmonics=16", "g-grid=" + grid, "t-max=0.05", "quiet=1"]
+    one = subprocess.run([solver_bin] + args + ["o=one.txt"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stdout + one.stderr
+    many = subprocess.run([solver_bin] + args + [f"ranks={ranks}", "o=slabs.txt"], cwd=tmp_path, capture_output=True,
+                          text=True, timeout=300, env={**os.environ, **({"SLB_FORCE_SLABS": "1"} if ranks == 1 else {})})
+    assert many.returncode == 0, many.stdout + many.stderr
+    a, b = (tmp_path / "one.txt").read_text().splitlines(), (tmp_path / "slabs.txt").read_text().splitlines()
+    assert len(a) == 22 and a == b
+    pick = lambda s: [l for l in s.splitlines() if l.startswith("# t=")]
+    assert pick(one.stdout) == pick(many.stdout) and len(pick(one.stdout)) == 11
+
+
 def test_program_over_ranks_refuses_what_it_does_not_do(tmp_path, solver_bin):
     args = ["E_dc=1", "E_omega=0.1", "mu=5", "alpha=1", "PhiYmin=-4", "PhiYmax=4", "omega=100", "B=0.5",
             "n-harmonics=8", "g-grid=500", "t-max=0.01", "o=stdout", "ranks=2"]
-    r = subprocess.run([solver_bin, "display=77"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=60)
-    assert r.returncode == 1 and "display=4 records only" in r.stderr
+    r = subprocess.run([solver_bin, "display=8"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "display=4 records and display=77 traces only" in r.stderr
     r = subprocess.run([solver_bin, "display=4"] + args[:-1] + ["ranks=0"], cwd=tmp_path, capture_output=True,
                        text=True, timeout=60)
     assert r.returncode == 1 and "Invalid value of ranks=" in r.stderr
