@@ -152,6 +152,8 @@ int slb_solver_halo_unpack_double(slb_solver *s, float *buf_left, float *buf_rig
  * nphi values of phi_x; out = nphi x (main_slab.j_last-j_first+1) floats on the host.
  * source 0: current lattice; 1: equilibrium a0 (cosine terms only) */
 int slb_solver_frame_values(slb_solver *s, int source, const float *phi_x, int nphi, float *out);
+/* the same with the values left on the device (d_out: nphi x columns floats) */
+int slb_solver_frame_values_device(slb_solver *s, int source, const float *phi_x, int nphi, float *d_out);
 
 /* copy rows [row0, row0+nrows) of device array `arr` (0 = a0, 1..4 = a[0..3],
  * 5..8 = b[0..3]) into dst as nrows x pitch floats */
@@ -237,7 +239,8 @@ void        slb_slabs_av_finish(slb_slabs *r, float av6[6]);
 void        slb_slabs_av_set(slb_slabs *r, const float av6[6]);
 float      *slb_slabs_av_data(slb_slabs *r);
 void        slb_slabs_gather_rows(slb_slabs *r, int arr, int row0, int nrows, float *dst);
-/* the display=4 / display=77 program over `nranks` processes, forked here (nothing may have touched a
+int         slb_slabs_write_frame(slb_slabs *r, const char *name, float t);   /* display=8 over slabs */
+/* the display=4 / display=8 / display=77 program over `nranks` processes, forked here (nothing may have touched a
  * GPU yet); parse_cmd() has run */
 int         slb_slab_main(int nranks);
 

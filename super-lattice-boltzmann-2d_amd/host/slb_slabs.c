@@ -478,6 +478,78 @@ void slb_slabs_gather_rows(slb_slabs *r, int arr, int row0, int nrows, float *ds
   }
 }
 
+/* The display=8 frame of the current main lattice (reference: src/boltzmann_solver.c:334-346,
+ * 487-507): every slab forms the values of its own columns on its GPU, a batch of phi_x
+ * values at a time; rank 0 puts the rows together and writes the file. */
+int slb_slabs_write_frame(slb_slabs *r, const char *name, float t)
+{
+  slb_solver *s = r->s;
+  slb_slabs_join(r);
+  HIP_OK(hipStreamSynchronize(r->main));
+  HIP_OK(hipStreamSynchronize(r->side));
+  const int total = s->M + 3, m1 = s->M + 1;
+  float phis[1024];
+  const int nphi = slb_frame_phi_x(phis, 1024);
+  if (nphi > 1024) return -1;
+  float *a01 = r->rank == 0 ? (float *)malloc(sizeof(float) * 2 * (size_t)total) : NULL;
+  slb_slabs_gather_rows(r, 1 + s->current, 0, 2, a01);
+  void *f = NULL;
+  if (r->rank == 0 && !(f = slb_frame_begin(name, t))) exit(EXIT_FAILURE);
+  int batch = (int)((16u << 20) / (unsigned)m1);
+  batch = batch < 8 ? 8 : (batch > 640 ? 640 : batch);
+  const int mine = s->main_slab.j_last - s->main_slab.j_first + 1;
+  const int base = s->M / r->nranks, rem = s->M % r->nranks;
+  float *d_mine = NULL, *d_all = NULL, *h_all = NULL, *line = NULL;
+  HIP_OK(hipMalloc((void **)&d_mine, sizeof(float) * (size_t)batch * mine));
+  if (r->rank == 0) {
+    HIP_OK(hipMalloc((void **)&d_all, sizeof(float) * (size_t)batch * m1));
+    h_all = (float *)malloc(sizeof(float) * (size_t)batch * m1);
+    line = (float *)malloc(sizeof(float) * (size_t)m1);
+  }
+  on_stream(r->main);
+  for (int p0 = 0; p0 < nphi; p0 += batch) {
+    const int np = nphi - p0 < batch ? nphi - p0 : batch;
+    check(slb_solver_frame_values_device(s, 0, phis + p0, np, d_mine), "the frame values");
+    if (r->rank != 0) {
+      slb_link_begin(r->link);
+      slb_link_send(r->link, 0, d_mine, (size_t)np * mine, r->main);
+      slb_link_end(r->link, r->main);
+      HIP_OK(hipStreamSynchronize(r->main));
+      continue;
+    }
+    /* rank q's block: np rows of its own columns, at offset np * (columns of the ranks before it) */
+    HIP_OK(hipMemcpyAsync(d_all, d_mine, sizeof(float) * (size_t)np * mine, hipMemcpyDeviceToDevice, r->main));
+    size_t off = (size_t)np * mine;
+    for (int q = 1; q < r->nranks; q++) {
+      const int w = base + (q < rem ? 1 : 0) + (q == r->nranks - 1 ? 1 : 0);
+      slb_link_begin(r->link);
+      slb_link_recv(r->link, q, d_all + off, (size_t)np * w, r->main);
+      slb_link_end(r->link, r->main);
+      off += (size_t)np * w;
+    }
+    HIP_OK(hipStreamSynchronize(r->main));
+    HIP_OK(hipMemcpy(h_all, d_all, sizeof(float) * (size_t)np * m1, hipMemcpyDeviceToHost));
+    for (int p = 0; p < np; p++) {
+      size_t blk = 0;
+      int col = 0;
+      for (int q = 0; q < r->nranks; q++) {
+        const int w = q == 0 ? mine : base + (q < rem ? 1 : 0) + (q == r->nranks - 1 ? 1 : 0);
+        memcpy(line + col, h_all + blk + (size_t)p * w, sizeof(float) * (size_t)w);
+        blk += (size_t)np * w;
+        col += w;
+      }
+      slb_frame_block(f, phis[p0 + p], line);
+    }
+  }
+  if (r->rank == 0) {
+    slb_frame_end(f, a01, total);
+    free(a01); free(h_all); free(line);
+    HIP_OK(hipFree(d_all));
+  }
+  HIP_OK(hipFree(d_mine));
+  return 0;
+}
+
 int slb_slabs_ranks_seen(slb_slabs *r) { return r->link ? slb_link_ranks_seen(r->link) : 1; }
 
 void slb_slabs_destroy(slb_slabs *r)
@@ -501,7 +573,7 @@ void slb_slabs_destroy(slb_slabs *r)
   free(r);
 }
 
-/* ---- the program over slabs: display=4 and display=77 ------------------------------------
+/* ---- the program over slabs: display=4, display=8 and display=77 --------------------------
  * One process per rank, forked before anything has touched a GPU.  Rank q takes device
  * `device` + q when the machine has that many, and the ranks talk over RCCL; with fewer
  * devices (a one-GPU box) the ranks share them and talk over sockets -- a rehearsal that
@@ -511,6 +583,7 @@ void slb_slabs_destroy(slb_slabs *r)
 static int step_kind(float t, float frame_time)
 {
   if (display == 77) return host_E_omega > 0 && frame_time >= 0.01 ? 2 : 0;
+  if (display == 8)  return 0;
   return host_E_omega > 0 && t >= t_start ? 1 : 0;
 }
 
@@ -627,6 +700,7 @@ static int rank_main(int rank, int nranks, const int *fds)
       slb_write_display4(norm, a012, b12, total, av6, T);
     }
   }
+  if (display == 8) slb_slabs_write_frame(r, "frame.data", t);
   if (rank == 0) slb_close_output();
   free(a012); free(b12);
   slb_slabs_destroy(r);
@@ -636,8 +710,8 @@ static int rank_main(int rank, int nranks, const int *fds)
 
 int slb_slab_main(int nranks)
 {
-  if (display != 4 && display != 77) {
-    fprintf(stderr, "ERROR: with ranks= the program writes display=4 records and display=77 traces only.\n");
+  if (display != 4 && display != 77 && display != 8) {
+    fprintf(stderr, "ERROR: with ranks= the program writes display=4 records, display=8 frames and display=77 traces only.\n");
     return EXIT_FAILURE;
   }
   if (display == 77 && host_N < 2) { fprintf(stderr, "ERROR: display=77 needs n-harmonics >= 2.\n"); return EXIT_FAILURE; }

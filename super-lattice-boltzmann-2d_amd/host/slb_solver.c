@@ -589,14 +589,13 @@ int slb_solver_copy_av_rows(slb_solver *s, float *rows)
  * source 1: the equilibrium coefficients a0, cosine terms only.  The cos/sin factors come from the host's
  * libm with the argument n*phi_x formed in float, as in the reference
  * (src/boltzmann_solver.c:495-504); the sums run on the device. */
-int slb_solver_frame_values(slb_solver *s, int source, const float *phi_x, int nphi, float *out)
+int slb_solver_frame_values_device(slb_solver *s, int source, const float *phi_x, int nphi, float *d_out)
 {
   const int nrows = s->N + 1;
   const int col_first = s->main_slab.j_first;
   const int ncols = s->main_slab.j_last - s->main_slab.j_first + 1;
   if (nphi < 1 || ncols < 1) return -1;
   const size_t tab_bytes = sizeof(double) * 2 * (size_t)nphi * nrows;
-  const size_t out_bytes = sizeof(float) * (size_t)nphi * ncols;
   double *tab = (double *)malloc(tab_bytes);
   if (!tab) return -1;
   for (int p = 0; p < nphi; p++)
@@ -605,19 +604,26 @@ int slb_solver_frame_values(slb_solver *s, int source, const float *phi_x, int n
       tab[2 * ((size_t)p * nrows + n) + 1] = sin(n * phi_x[p]);
     }
   double *d_tab = NULL;
-  float  *d_out = NULL;
   HIP_OK(hipMalloc((void **)&d_tab, tab_bytes));
-  HIP_OK(hipMalloc((void **)&d_out, out_bytes));
   HIP_OK(hipMemcpy(d_tab, tab, tab_bytes, hipMemcpyHostToDevice));
   free(tab);
   const int rc = source == 1
       ? slb_frame_values(s->a0, NULL, s->pitch, nrows, col_first, ncols, d_tab, nphi, d_out)
       : slb_frame_values(s->a[s->current], s->b[s->current], s->pitch, nrows, col_first, ncols, d_tab, nphi, d_out);
-  if (rc == 0) {
-    HIP_OK(hipStreamSynchronize((hipStream_t)slb_get_stream()));
-    HIP_OK(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
-  }
+  if (rc == 0) HIP_OK(hipStreamSynchronize((hipStream_t)slb_get_stream()));
   HIP_OK(hipFree(d_tab));
+  return rc;
+}
+
+int slb_solver_frame_values(slb_solver *s, int source, const float *phi_x, int nphi, float *out)
+{
+  const int ncols = s->main_slab.j_last - s->main_slab.j_first + 1;
+  if (nphi < 1 || ncols < 1) return -1;
+  const size_t out_bytes = sizeof(float) * (size_t)nphi * ncols;
+  float *d_out = NULL;
+  HIP_OK(hipMalloc((void **)&d_out, out_bytes));
+  const int rc = slb_solver_frame_values_device(s, source, phi_x, nphi, d_out);
+  if (rc == 0) HIP_OK(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
   HIP_OK(hipFree(d_out));
   return rc;
 }

@@ -54,11 +54,29 @@ def test_program_over_ranks_writes_the_single_gpu_trace(ranks, grid, tmp_path, s
     assert pick(one.stdout) == pick(many.stdout) and len(pick(one.stdout)) == 11
 
 
+@pytest.mark.parametrize("ranks,grid", [(3, "61"), (4, "2500")])
+def test_program_over_ranks_writes_the_single_gpu_frame(ranks, grid, tmp_path, solver_bin):
+    """display=8 over ranks: every slab forms the frame values of its columns, rank 0 writes
+    frame.data; the file equals the single-GPU program's byte for byte."""
+    args = ["display=8", "E_dc=1", "E_omega=0.1", "omega=100", "mu=5", "alpha=1", "B=0.5", "PhiYmin=-4",
+            "PhiYmax=4", "dt=0.001", "n-harmonics=8", "g-grid=" + grid, "t-max=0.01", "quiet=1", "o=out.txt"]
+    (tmp_path / "one").mkdir(), (tmp_path / "many").mkdir()
+    one = subprocess.run([solver_bin] + args, cwd=tmp_path / "one", capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stdout + one.stderr
+    many = subprocess.run([solver_bin] + args + [f"ranks={ranks}"], cwd=tmp_path / "many", capture_output=True,
+                          text=True, timeout=300)
+    assert many.returncode == 0, many.stdout + many.stderr
+    a, b = (tmp_path / "one" / "frame.data").read_bytes(), (tmp_path / "many" / "frame.data").read_bytes()
+    assert len(a.splitlines()) == 629 * (int(grid) + 1) + 2
+    assert a == b
+    assert [l for l in one.stdout.splitlines() if "norm" in l] == [l for l in many.stdout.splitlines() if "norm" in l]
+
+
 def test_program_over_ranks_refuses_what_it_does_not_do(tmp_path, solver_bin):
     args = ["E_dc=1", "E_omega=0.1", "mu=5", "alpha=1", "PhiYmin=-4", "PhiYmax=4", "omega=100", "B=0.5",
             "n-harmonics=8", "g-grid=500", "t-max=0.01", "o=stdout", "ranks=2"]
-    r = subprocess.run([solver_bin, "display=8"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=60)
-    assert r.returncode == 1 and "display=4 records and display=77 traces only" in r.stderr
+    r = subprocess.run([solver_bin, "display=7"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "display=4 records, display=8 frames and display=77 traces only" in r.stderr
     r = subprocess.run([solver_bin, "display=4"] + args[:-1] + ["ranks=0"], cwd=tmp_path, capture_output=True,
                        text=True, timeout=60)
     assert r.returncode == 1 and "Invalid value of ranks=" in r.stderr
