@@ -201,6 +201,7 @@ def lib():
         L.slb_link_end.argtypes, L.slb_link_end.restype = [vp, vp], None
         L.slb_link_close.argtypes, L.slb_link_close.restype = [vp], None
         L.slb_slabs_create.argtypes, L.slb_slabs_create.restype = [i, i, vp], vp
+        L.slb_slabs_create_loopback.argtypes, L.slb_slabs_create_loopback.restype = [i, i, vp], vp
         L.slb_slabs_destroy.argtypes, L.slb_slabs_destroy.restype = [vp], None
         L.slb_slabs_solver.argtypes, L.slb_slabs_solver.restype = [vp], C.POINTER(SolverStruct)
         L.slb_slabs_main_stream.argtypes, L.slb_slabs_main_stream.restype = [vp], vp

@@ -628,11 +628,14 @@ struct Fused2Args {
 // ROWS: the three rows av() reads (a rows 0 and 1, b row 1) of BOTH new main lattices are
 // also written to small side buffers, so the harmonic sums of the in-between time step can
 // be formed although that lattice itself is never stored.
-template <int MINW, bool DIAG = false, bool ROWS = false>
+// H: halo lanes per side of a wave (1 suffices for the three hand-offs; 4 puts the 56 interior
+// lanes' stores -- 896 bytes per row -- on 128-byte line boundaries, at the price of forming
+// 8 of 64 columns twice instead of 2)
+template <int MINW, bool DIAG = false, bool ROWS = false, int H = 1>
 __global__ void __launch_bounds__(256, MINW)
 fused2_step_kernel(const Fused2Args p)
 {
-  constexpr int V = 4;
+  constexpr int V = 4, INNER = 64 - 2 * H;
   const int lane = threadIdx.x & 63;
   // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one).  Neighbouring
   // column strips overlap by their halo lanes, so strips that are adjacent in memory are
@@ -651,12 +654,12 @@ fused2_step_kernel(const Fused2Args p)
   if (bx < (per_xcd << 3)) bx = (bx & 7) * per_xcd + (bx >> 3);
   bx += p.g0[ph];
   const int wave = (bx * blockDim.x + threadIdx.x) >> 6;
-  const int jj   = p.jj0 + (wave * 62 + lane - 1) * V;          // first own column (may be < 0)
+  const int jj   = p.jj0 + (wave * INNER + lane - H) * V;       // first own column (may be < 0)
   int j_hi = p.jl[0];
 #pragma unroll
   for (int q = 1; q < 4; q++) j_hi = p.jl[q] > j_hi ? p.jl[q] : j_hi;
-  if (p.jj0 + wave * 62 * V > j_hi) return;                     // whole wave past the end
-  const bool interior = lane >= 1 && lane <= 62;
+  if (p.jj0 + wave * INNER * V > j_hi) return;                  // whole wave past the end
+  const bool interior = lane >= H && lane < 64 - H;
   const int jcl = jj < 0 ? 0 : (jj > p.pitch - V ? p.pitch - V : jj);
   const unsigned j = (unsigned)jcl;
 
@@ -1666,18 +1669,18 @@ int resident_workgroups(K kernel, int block)
 // their rows in one workgroup each -- such a workgroup reads every input row once and forms
 // no row twice -- and only the groups left over are cut into chunks (`tail_chunk` rows);
 // narrower lattices are cut into chunks of `tail_chunk` rows throughout.
-template <int MINW, bool DIAG = false, bool ROWS = false>
+template <int MINW, bool DIAG = false, bool ROWS = false, int H = 1>
 int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
 {
   int lo = args.jf[0], hi = args.jl[0];
   for (int q = 1; q < 4; q++) { lo = args.jf[q] < lo ? args.jf[q] : lo; hi = args.jl[q] > hi ? args.jl[q] : hi; }
-  args.jj0 = lo / 4 * 4;
-  const int per_wave = 62 * 4;
+  args.jj0 = H == 1 ? lo / 4 * 4 : lo / 32 * 32;         // wide halos: strips start on line boundaries
+  const int per_wave = (64 - 2 * H) * 4;
   const int waves = (hi + 1 - args.jj0 + per_wave - 1) / per_wave;
   const int wpb = block / 64;
   const int groups = (waves + wpb - 1) / wpb;
   auto chunks_of = [&](int len) { return (args.N + len - 1) / len; };
-  const int slots = n_chunk > 0 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS>, block);
+  const int slots = n_chunk > 0 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS, H>, block);
   // (measured on MI355X, 128 rows: with 11 rounds of workgroups -- 2^23 columns -- whole
   // groups first is 2 % faster than cutting every group; with 1.4 rounds -- 2^20 columns --
   // it is no faster although it moves 5 % fewer bytes, and at 512 rows 5 % slower: the
@@ -1698,7 +1701,7 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
     args.wg_begin[2] = args.wg_begin[1] + (groups - whole) * chunks_of(tail_chunk);
   }
   for (int k = args.n_phase; k < 3; k++) { args.g0[k] = 0; args.ng[k] = 1; args.len[k] = args.N; args.wg_begin[k + 1] = args.wg_begin[k]; }
-  hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS>), dim3(args.wg_begin[args.n_phase]), dim3(block), 0,
+  hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS, H>), dim3(args.wg_begin[args.n_phase]), dim3(block), 0,
                      g_stream, args);
   return (int)hipGetLastError();
 }
@@ -1950,6 +1953,8 @@ int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
   switch (g_variant) {
     case 21: return launch_fused2<2>(s, block, n_chunk, tail_chunk);   // register budget of 2, 3 (default), 4 waves per SIMD
     case 25: return launch_fused2<4>(s, block, n_chunk, tail_chunk);
+    case 29: return launch_fused2<3, false, false, 2>(s, block, n_chunk, tail_chunk);   // two, four halo lanes per side
+    case 30: return launch_fused2<3, false, false, 4>(s, block, n_chunk, tail_chunk);
 #ifdef SLB_TIMING_VARIANTS
     case 98: return launch_fused2<3, true>(s, block, n_chunk, tail_chunk);   // arithmetic removed: memory floor, wrong results
 #endif

@@ -221,6 +221,7 @@ void      slb_link_close(slb_link *l);
  * slb_slabs_main_stream() is the one the interior launches use. */
 typedef struct slb_slabs slb_slabs;
 slb_slabs  *slb_slabs_create(int rank, int nranks, slb_link *link);
+slb_slabs  *slb_slabs_create_loopback(int rank, int nranks, slb_link *link);   /* timing aid, see slb_slabs.c */
 void        slb_slabs_destroy(slb_slabs *r);
 slb_solver *slb_slabs_solver(slb_slabs *r);
 void       *slb_slabs_main_stream(slb_slabs *r);

@@ -56,7 +56,7 @@ typedef struct {
 struct slb_slabs {
   slb_solver *s;
   slb_link   *link;
-  int rank, nranks, left, right;
+  int rank, nranks, left, right;    /* left, right: the neighbours' ranks in the link, -1: none  */
   hipStream_t main, side, av;
   hipEvent_t  ev_main, ev_side, ev_x;
   int   side_busy;
@@ -80,7 +80,24 @@ static void check(int rc, const char *what)
 
 static av_batch *batch_at(slb_slabs *r, long b) { return &r->ring[b % r->ring_n]; }
 
+static slb_slabs *slabs_create(int rank, int nranks, slb_link *link, int loopback);
+
 slb_slabs *slb_slabs_create(int rank, int nranks, slb_link *link)
+{
+  return slabs_create(rank, nranks, link, 0);
+}
+
+/* For measuring what the driver and the transport cost on ONE GPU: the slab of rank `rank`
+ * of `nranks` with both neighbours' messages addressed to this process itself (link: an
+ * RCCL communicator of one rank).  The ghost columns then hold this slab's own edge columns,
+ * so the lattice is not the physical one; launches, messages and their ordering are those
+ * of a real run.  No av chain. */
+slb_slabs *slb_slabs_create_loopback(int rank, int nranks, slb_link *link)
+{
+  return slabs_create(rank, nranks, link, 1);
+}
+
+static slb_slabs *slabs_create(int rank, int nranks, slb_link *link, int loopback)
 {
   if (nranks > 1 && !link) { fprintf(stderr, "slb_slabs_create: %d ranks need a link\n", nranks); return NULL; }
   slb_slabs *r = (slb_slabs *)calloc(1, sizeof(*r));
@@ -88,6 +105,10 @@ slb_slabs *slb_slabs_create(int rank, int nranks, slb_link *link)
   r->rank = rank; r->nranks = nranks; r->link = link;
   r->left = rank > 0 ? rank - 1 : -1;
   r->right = rank < nranks - 1 ? rank + 1 : -1;
+  if (loopback) {
+    if (r->left >= 0) r->left = slb_link_rank(link);
+    if (r->right >= 0) r->right = slb_link_rank(link);
+  }
   r->s = slb_solver_create(rank, nranks);
   if (!r->s) { free(r); return NULL; }
   /* not the legacy null stream: its implicit synchronisation with other streams would
