@@ -14,7 +14,8 @@
  * per call (one small workspace is allocated on first use of av() and
  * slb_av_partial()).
  * Launches are asynchronous on the stream set by slb_set_stream() (default: the
- * null stream, as in the reference).
+ * null stream, as in the reference), or on the one the calling thread has pushed
+ * with slb_push_stream().
  *
  * Like the reference's boundary the library is meant for ONE host thread per
  * process and one GPU per process: load_data(), slb_set_stream(), slb_set_av_mode()
@@ -297,9 +298,16 @@ int slb_seq_sum_stats(const float *x, int n, float *out, int *stats);
 int slb_static_init(void);
 int slb_av_static(float *a, float *b, float *av_data, float t);
 
-/* Stream for every launch of this library (a hipStream_t passed as void*). */
+/* Launch stream (a hipStream_t passed as void*).  slb_set_stream() sets the default of the
+ * whole process (the reference's boundary has no stream argument; default: the null stream).
+ * slb_push_stream() makes a stream the launch stream of the CALLING THREAD until the matching
+ * slb_pop_stream() (up to 8 nested): a host that works with several streams brackets each
+ * call with the stream it is meant for instead of changing process-wide state.
+ * slb_get_stream(): where the calling thread's next launch would go. */
 void  slb_set_stream(void *hip_stream);
 void *slb_get_stream(void);
+void  slb_push_stream(void *hip_stream);
+void  slb_pop_stream(void);
 
 /* Kernel selection and launch shape, for tuning; 0 = let the library choose.
  * variant, slb_sweep: 1 = one column per lane (any pitch), 2 = four columns per

@@ -27,7 +27,7 @@ ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "Handle
                  "slb_sweep", "slb_step_fused", "slb_step_fused2", "slb_step_fused2_rows", "slb_step_multi",
                  "slb_av_sums_exact", "slb_av_sums_exact_n", "slb_av_sums_exact_from_n", "slb_av_update_exact", "slb_halo_pack", "slb_halo_unpack", "slb_halo_pack_segs", "slb_halo_unpack_segs", "slb_av_partial",
                  "slb_frame_values", "slb_seq_sum", "slb_seq_sum_stats",
-                 "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream",
+                 "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream", "slb_push_stream", "slb_pop_stream",
                  "slb_set_tuning", "slb_version", "slb_static_init", "slb_av_static")
 ABI_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha",
                "PhiYmin", "PhiYmax", "host_B", "t_start", "host_dPhi", "host_dt",
@@ -71,7 +71,8 @@ class SolverStruct(C.Structure):
                 ("t", C.c_float), ("frame_time", C.c_float), ("steps", C.c_long), ("fused", C.c_int),
                 ("G", C.c_int),
                 ("spare_a", C.c_void_p), ("spare_b", C.c_void_p), ("spare_ah", C.c_void_p),
-                ("spare_bh", C.c_void_p), ("spare_of", C.c_int), ("spare_of_hs", C.c_int)]
+                ("spare_bh", C.c_void_p), ("spare_of", C.c_int), ("spare_of_hs", C.c_int),
+                ("stream", C.c_void_p), ("has_stream", C.c_int)]
 
 
 _lib = None
@@ -120,6 +121,8 @@ def lib():
         L.slb_seq_sum_stats.argtypes, L.slb_seq_sum_stats.restype = [fp, i, fp, fp], i
         L.slb_set_stream.argtypes, L.slb_set_stream.restype = [vp], None
         L.slb_get_stream.argtypes, L.slb_get_stream.restype = [], vp
+        L.slb_push_stream.argtypes, L.slb_push_stream.restype = [vp], None
+        L.slb_pop_stream.argtypes, L.slb_pop_stream.restype = [], None
         L.slb_set_tuning.argtypes, L.slb_set_tuning.restype = [i, i, i], None
         L.slb_version.argtypes, L.slb_version.restype = [], C.c_char_p
         # host engine

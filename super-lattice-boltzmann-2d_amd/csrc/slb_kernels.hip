@@ -34,7 +34,12 @@ struct Physics {
   bool  loaded;
 };
 Physics     g_phys = {};
-hipStream_t g_stream = nullptr;
+hipStream_t g_stream = nullptr;      // slb_set_stream(): the default launch stream of the process
+// slb_push_stream(): the launch stream of the calling thread while the push is in force
+constexpr int kStreamStack = 8;
+thread_local hipStream_t t_stream[kStreamStack];
+thread_local int         t_stream_depth = 0;
+inline hipStream_t launch_stream() { return t_stream_depth > 0 ? t_stream[t_stream_depth - 1] : g_stream; }
 int         g_av_mode = SLB_AV_EXACT;
 int         g_variant = 0, g_n_chunk = 0, g_block = 0;
 double     *g_ws = nullptr;          // reduction workspace, allocated once
@@ -1614,7 +1619,7 @@ int launch_sweep(SweepArgs &args, int block)
   const int cols   = args.j_last + 1 - args.jj0;          // columns jj0..j_last get a lane
   const int lanes  = (cols + V - 1) / V;
   dim3 grid((lanes + block - 1) / block, (args.N + args.n_chunk - 1) / args.n_chunk);
-  hipLaunchKernelGGL((sweep_kernel<V, XCH>), grid, dim3(block), 0, g_stream, args);
+  hipLaunchKernelGGL((sweep_kernel<V, XCH>), grid, dim3(block), 0, launch_stream(), args);
   return (int)hipGetLastError();
 }
 
@@ -1625,7 +1630,7 @@ int launch_pipe(SweepArgs &args, int block)
   const int cols  = args.j_last + 1 - args.jj0;
   const int lanes = (cols + 3) / 4;
   dim3 grid((lanes + block - 1) / block, (args.N + args.n_chunk - 1) / args.n_chunk);
-  hipLaunchKernelGGL((sweep_pipe_kernel<NT>), grid, dim3(block), 0, g_stream, args);
+  hipLaunchKernelGGL((sweep_pipe_kernel<NT>), grid, dim3(block), 0, launch_stream(), args);
   return (int)hipGetLastError();
 }
 
@@ -1639,7 +1644,7 @@ int launch_fused(FusedArgs &args, int block)
   const int waves = (hi + 1 - args.jj0 + per_wave - 1) / per_wave;
   const int wpb = block / 64;
   dim3 grid((waves + wpb - 1) / wpb, (args.N + args.n_chunk - 1) / args.n_chunk);
-  hipLaunchKernelGGL((fused_step_kernel<NT, MINW, DIAG>), grid, dim3(block), 0, g_stream, args);
+  hipLaunchKernelGGL((fused_step_kernel<NT, MINW, DIAG>), grid, dim3(block), 0, launch_stream(), args);
   return (int)hipGetLastError();
 }
 
@@ -1702,7 +1707,7 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
   }
   for (int k = args.n_phase; k < 3; k++) { args.g0[k] = 0; args.ng[k] = 1; args.len[k] = args.N; args.wg_begin[k + 1] = args.wg_begin[k]; }
   hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS, H>), dim3(args.wg_begin[args.n_phase]), dim3(block), 0,
-                     g_stream, args);
+                     launch_stream(), args);
   return (int)hipGetLastError();
 }
 
@@ -1731,7 +1736,7 @@ int launch_multi(const slb_multi_geom *g, const float *a0, const float *const *i
   const int waves = (hi + 1 - s.jj0 + per_wave - 1) / per_wave;
   const int wpb = block / 64;
   dim3 grid((waves + wpb - 1) / wpb, (s.N + s.n_chunk - 1) / s.n_chunk);
-  hipLaunchKernelGGL((multi_step_kernel<S, V, MINW, DIAG>), grid, dim3(block), 0, g_stream, s);
+  hipLaunchKernelGGL((multi_step_kernel<S, V, MINW, DIAG>), grid, dim3(block), 0, launch_stream(), s);
   return (int)hipGetLastError();
 }
 
@@ -1762,7 +1767,16 @@ void load_data(void)
 }
 
 void slb_set_stream(void *s)           { g_stream = (hipStream_t)s; }
-void *slb_get_stream(void)             { return (void *)g_stream; }
+void *slb_get_stream(void)             { return (void *)launch_stream(); }
+void slb_push_stream(void *s)
+{
+  if (t_stream_depth >= kStreamStack) { fprintf(stderr, "slb_push_stream: more than %d nested\n", kStreamStack); exit(EXIT_FAILURE); }
+  t_stream[t_stream_depth++] = (hipStream_t)s;
+}
+void slb_pop_stream(void)
+{
+  if (t_stream_depth > 0) t_stream_depth--;
+}
 void slb_set_av_mode(int mode)         { g_av_mode = (mode == SLB_AV_TREE || mode == SLB_AV_CHAIN) ? mode : SLB_AV_EXACT; }
 void slb_set_tuning(int v, int nc, int b) { g_variant = v; g_n_chunk = nc; g_block = b; }
 const char *slb_version(void)          { return "slb2d-gfx950 0.1"; }
@@ -2043,7 +2057,7 @@ int slb_halo_pack(const float *a, const float *b, int pitch, int nrows, int col,
 {
   if (nrows < 1 || ncols < 1 || col < 0 || col + ncols > pitch) return -1;
   const int n = 2 * ncols * nrows;
-  hipLaunchKernelGGL(halo_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, a, b, pitch, nrows, col, ncols, buf);
+  hipLaunchKernelGGL(halo_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, launch_stream(), a, b, pitch, nrows, col, ncols, buf);
   return (int)hipGetLastError();
 }
 
@@ -2051,7 +2065,7 @@ int slb_halo_unpack(float *a, float *b, int pitch, int nrows, int col, int ncols
 {
   if (nrows < 1 || ncols < 1 || col < 0 || col + ncols > pitch) return -1;
   const int n = 2 * ncols * nrows;
-  hipLaunchKernelGGL(halo_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, g_stream, a, b, pitch, nrows, col, ncols, buf);
+  hipLaunchKernelGGL(halo_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, launch_stream(), a, b, pitch, nrows, col, ncols, buf);
   return (int)hipGetLastError();
 }
 
@@ -2068,8 +2082,8 @@ static int halo_segs(const slb_halo_seg *segs, int nsegs, int pitch, int nrows, 
     h.start[k + 1] = h.start[k] + 2 * segs[k].ncols * nrows;
   }
   const int n = h.start[nsegs];
-  if (pack) hipLaunchKernelGGL(halo_segs_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, g_stream, h);
-  else      hipLaunchKernelGGL(halo_segs_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, g_stream, h);
+  if (pack) hipLaunchKernelGGL(halo_segs_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, launch_stream(), h);
+  else      hipLaunchKernelGGL(halo_segs_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, launch_stream(), h);
   return (int)hipGetLastError();
 }
 
@@ -2094,9 +2108,9 @@ int slb_frame_values(const float *a, const float *b, int pitch, int nrows, int c
   if (!aligned16(cs)) { fprintf(stderr, "slb_frame_values: table must be 16-byte aligned\n"); return -1; }
   constexpr int P = 8;
   dim3 grid((ncols + 255) / 256, (nphi + P - 1) / P);
-  if (b) hipLaunchKernelGGL((frame_kernel<P, true>), grid, dim3(256), 0, g_stream, a, b, pitch, nrows, col_first,
+  if (b) hipLaunchKernelGGL((frame_kernel<P, true>), grid, dim3(256), 0, launch_stream(), a, b, pitch, nrows, col_first,
                             ncols, reinterpret_cast<const double2 *>(cs), nphi, out);
-  else   hipLaunchKernelGGL((frame_kernel<P, false>), grid, dim3(256), 0, g_stream, a, b, pitch, nrows, col_first,
+  else   hipLaunchKernelGGL((frame_kernel<P, false>), grid, dim3(256), 0, launch_stream(), a, b, pitch, nrows, col_first,
                             ncols, reinterpret_cast<const double2 *>(cs), nphi, out);
   return (int)hipGetLastError();
 }
@@ -2105,7 +2119,7 @@ int slb_seq_sum_stats(const float *x, int n, float *out, int *stats)
 {
   if (n < 0 || (n > 0 && !x) || !out) return -1;
   // slb_set_tuning variants 41..47 select other workgroup shapes (waves x terms per thread)
-#define SLB_SEQ(W, T) hipLaunchKernelGGL((seq_sum_kernel<W, T>), dim3(1), dim3(64 * W), 0, g_stream, x, n, out, stats)
+#define SLB_SEQ(W, T) hipLaunchKernelGGL((seq_sum_kernel<W, T>), dim3(1), dim3(64 * W), 0, launch_stream(), x, n, out, stats)
   switch (g_variant) {
     case 41: SLB_SEQ(4, 4); break;
     case 42: SLB_SEQ(8, 4); break;
@@ -2138,8 +2152,8 @@ static int av_partial_ws(const slb_slab *slab, const float *a, const float *b, d
   const int cols = slab->j_last - slab->j_first + 1;
   int nb = cols > 0 ? (cols + kAvColsPerBlock - 1) / kAvColsPerBlock : 1;
   if (nb > kMaxAvBlocks) nb = kMaxAvBlocks;
-  hipLaunchKernelGGL(av_partial_kernel, dim3(nb), dim3(256), 0, g_stream, p, ws);
-  hipLaunchKernelGGL(av_combine_kernel, dim3(1), dim3(64), 0, g_stream, (const double *)ws, nb, sums);
+  hipLaunchKernelGGL(av_partial_kernel, dim3(nb), dim3(256), 0, launch_stream(), p, ws);
+  hipLaunchKernelGGL(av_combine_kernel, dim3(1), dim3(64), 0, launch_stream(), (const double *)ws, nb, sums);
   return (int)hipGetLastError();
 }
 
@@ -2155,7 +2169,7 @@ int slb_av_update(const double *sums, float *av_data, float t)
 {
   if (!g_phys.loaded) return -1;
   const float wt = g_phys.omega * t;            // float product, as the reference forms it
-  hipLaunchKernelGGL(av_update_kernel, dim3(1), dim3(64), 0, g_stream, sums, av_data,
+  hipLaunchKernelGGL(av_update_kernel, dim3(1), dim3(64), 0, launch_stream(), sums, av_data,
                      cos((double)wt), sin((double)wt), g_phys.dt);
   return (int)hipGetLastError();
 }
@@ -2176,9 +2190,9 @@ int slb_av_sums_exact_from_n(const slb_slab *slab, int n, const float *const a[]
   // both kernels give the CPU's bits; below a few ten thousand columns the one-lane chain is
   // done before the parallel form has paid for its passes
   if (g_av_mode == SLB_AV_CHAIN || slab->j_last - slab->j_first < 32768)
-    hipLaunchKernelGGL(av_exact_kernel, dim3(3 * n), dim3(64), 0, g_stream, sets);
+    hipLaunchKernelGGL(av_exact_kernel, dim3(3 * n), dim3(64), 0, launch_stream(), sets);
   else
-    hipLaunchKernelGGL(av_exact_scan_kernel, dim3(3 * n), dim3(64 * kAvScanWaves), 0, g_stream, sets);
+    hipLaunchKernelGGL(av_exact_scan_kernel, dim3(3 * n), dim3(64 * kAvScanWaves), 0, launch_stream(), sets);
   return (int)hipGetLastError();
 }
 
@@ -2197,7 +2211,7 @@ int slb_av_update_exact(const float *tot3, float *av_data, float t)
 {
   if (!g_phys.loaded || !tot3 || !av_data) return -1;
   const float wt = g_phys.omega * t;            // float product, as the reference forms it
-  hipLaunchKernelGGL(av_update_exact_kernel, dim3(1), dim3(64), 0, g_stream, tot3, av_data,
+  hipLaunchKernelGGL(av_update_exact_kernel, dim3(1), dim3(64), 0, launch_stream(), tot3, av_data,
                      cos((double)wt), sin((double)wt), g_phys.dt);
   return (int)hipGetLastError();
 }

@@ -58,6 +58,10 @@ typedef struct slb_solver {
    * never-written cells mirror a/b[spare_of] and a/b[spare_of_hs] */
   float *spare_a, *spare_b, *spare_ah, *spare_bh;
   int   spare_of, spare_of_hs;
+  /* launch stream of this object's calls (slb_solver_set_stream); without one they go where
+   * the calling thread's launches go (slb_push_stream / slb_set_stream) */
+  void *stream;
+  int   has_stream;
 } slb_solver;
 
 /* Allocate the slab of rank `rank` of `nranks`, build a0 for its columns
@@ -66,6 +70,8 @@ typedef struct slb_solver {
  * call slb_derive_and_load() first.  Returns NULL after printing the reason. */
 slb_solver *slb_solver_create(int rank, int nranks);
 void        slb_solver_destroy(slb_solver *s);
+/* every later launch of this solver's calls goes to `hip_stream` (a hipStream_t) */
+void        slb_solver_set_stream(slb_solver *s, void *hip_stream);
 
 /* the tiptoe half step (reference: src/boltzmann_solver.c:158-165) */
 void slb_solver_tiptoe(slb_solver *s);

@@ -286,7 +286,7 @@ static void av_ring_flush(slb_solver *s)
   }
   HIP_OK(hipEventRecord(ev_rows, NULL));
   HIP_OK(hipStreamWaitEvent(st, ev_rows, 0));
-  slb_set_stream(st);
+  slb_push_stream(st);
   int rc = slb_av_sums_exact_n(&av_cols, av_n_pending, a, b, tot);
   if (rc != 0) { fprintf(stderr, "ERROR: av sums failed (%d)\n", rc); exit(EXIT_FAILURE); }
   for (int i = 0; i < av_n_pending && rc == 0; i++) {
@@ -298,7 +298,7 @@ static void av_ring_flush(slb_solver *s)
   if (rc != 0) { fprintf(stderr, "ERROR: av update failed (%d)\n", rc); exit(EXIT_FAILURE); }
   HIP_OK(hipEventRecord(ev_batch, st));
   av_batch_out = 1;
-  slb_set_stream(NULL);
+  slb_pop_stream();
   av_n_pending = 0;
 }
 
@@ -323,7 +323,7 @@ static void av_ring_submit(slb_solver *s, int n, const float *t)
   int rc = 0;
   HIP_OK(hipEventRecord(ev_rows, NULL));
   HIP_OK(hipStreamWaitEvent(st, ev_rows, 0));
-  slb_set_stream(st);
+  slb_push_stream(st);
   for (int i = 0; i < n && rc == 0; i++) {
     const int k = (int)((av_index + i) % AV_SLOTS);
     rc = slb_av_partial(&av_cols, av_slot[k].rows, av_slot[k].rows + s->pitch, av_slot[k].sums);
@@ -332,7 +332,7 @@ static void av_ring_submit(slb_solver *s, int n, const float *t)
     av_slot[k].used = 1;
   }
   if (rc != 0) { fprintf(stderr, "ERROR: av sums failed (%d)\n", rc); exit(EXIT_FAILURE); }
-  slb_set_stream(NULL);
+  slb_pop_stream();
   av_index += n;
 }
 

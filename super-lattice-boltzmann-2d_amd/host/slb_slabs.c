@@ -137,7 +137,7 @@ static slb_slabs *slabs_create(int rank, int nranks, slb_link *link, int loopbac
     HIP_OK(hipEventCreateWithFlags(&r->ring[k].done, hipEventDisableTiming));
   }
   HIP_OK(hipDeviceSynchronize());
-  slb_set_stream(r->main);
+  slb_solver_set_stream(r->s, r->main);
   return r;
 }
 
@@ -193,7 +193,9 @@ static void exchange(slb_slabs *r, float *const send[2], float *const recv[2], s
 }
 
 /* ---- stepping --------------------------------------------------------------------------- */
-static void on_stream(hipStream_t st) { slb_set_stream((void *)st); }
+/* the engine's launches from here on go to this stream (state of this slab's solver
+ * object, not of the process) */
+#define on_stream(st) slb_solver_set_stream(r->s, (void *)(st))
 
 /* first half step, then the ghost columns of the new half-step lattice (the main
  * lattice's are from the initial state) */
@@ -358,13 +360,12 @@ static void av_launch_ready(slb_slabs *r)
     /* the rows were written by the interior launch and the edge launches of their double steps */
     HIP_OK(hipStreamWaitEvent(r->av, r->ev_main, 0));
     if (r->side_busy) HIP_OK(hipStreamWaitEvent(r->av, r->ev_side, 0));
-    void *before = slb_get_stream();
-    on_stream(r->av);
+    slb_push_stream(r->av);
     check(slb_av_sums_exact_from_n(&r->s->av_slab, b->n, a, bb, ini, tot), "the sums of av()");
     if (r->right < 0)
       for (int k = 0; k < b->n; k++) check(slb_av_update_exact(b->tot + 3 * k, r->av_data, b->t[k]), "the update of av()");
+    slb_pop_stream();
     HIP_OK(hipEventRecord(b->done, r->av));
-    slb_set_stream(before);
     b->summed = 1;
     r->batch_next_sum++;
   }
@@ -577,7 +578,6 @@ void slb_slabs_destroy(slb_slabs *r)
 {
   if (!r) return;
   HIP_OK(hipDeviceSynchronize());
-  slb_set_stream(NULL);
   for (int k = 0; k < r->ring_n; k++) {
     for (int q = 0; q < AVC_SETS; q++) if (r->ring[k].rows[q]) hipFree(r->ring[k].rows[q]);
     if (r->ring[k].init) { hipFree(r->ring[k].init); hipFree(r->ring[k].tot); }

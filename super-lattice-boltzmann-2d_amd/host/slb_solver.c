@@ -164,6 +164,21 @@ void slb_solver_destroy(slb_solver *s)
   free(s);
 }
 
+void slb_solver_set_stream(slb_solver *s, void *hip_stream)
+{
+  s->stream = hip_stream;
+  s->has_stream = 1;
+}
+
+/* a launch of the library on this solver's stream: ON(s, rc = slb_sweep(...)); */
+#define ON(s, statement) \
+  do { if ((s)->has_stream) slb_push_stream((s)->stream); statement; if ((s)->has_stream) slb_pop_stream(); } while (0)
+/* the stream this solver's launches go to */
+static hipStream_t stream_of(const slb_solver *s)
+{
+  return (hipStream_t)(s->has_stream ? s->stream : slb_get_stream());
+}
+
 static void check_sweep(int rc, int line)
 {
   if (rc > 0) HandleError(rc, __FILE__, line);
@@ -180,23 +195,23 @@ void slb_solver_tiptoe(slb_solver *s)
 {
   const float c0 = 1;
   const float c1 = cos(host_omega * (host_dt));
-  check_sweep(slb_sweep(&s->main_slab, s->a0, s->a[s->current], s->b[s->current],
+  { int rc_; ON(s, rc_ = slb_sweep(&s->main_slab, s->a0, s->a[s->current], s->b[s->current],
                         s->a[s->current], s->b[s->current],
-                        s->a[s->current_hs], s->b[s->current_hs], c0, c1), __LINE__);
+                        s->a[s->current_hs], s->b[s->current_hs], c0, c1)); check_sweep(rc_, __LINE__); }
 }
 
 void slb_solver_sweep_main(slb_solver *s, float c0, float c1)
 {
-  check_sweep(slb_sweep(&s->main_slab, s->a0, s->a[s->current], s->b[s->current],
+  { int rc_; ON(s, rc_ = slb_sweep(&s->main_slab, s->a0, s->a[s->current], s->b[s->current],
                         s->a[s->current_hs], s->b[s->current_hs],
-                        s->a[s->next], s->b[s->next], c0, c1), __LINE__);
+                        s->a[s->next], s->b[s->next], c0, c1)); check_sweep(rc_, __LINE__); }
 }
 
 void slb_solver_sweep_half(slb_solver *s, float c0, float c1)
 {
-  check_sweep(slb_sweep(&s->half_slab, s->a0, s->a[s->current_hs], s->b[s->current_hs],
+  { int rc_; ON(s, rc_ = slb_sweep(&s->half_slab, s->a0, s->a[s->current_hs], s->b[s->current_hs],
                         s->a[s->next], s->b[s->next],
-                        s->a[s->next_hs], s->b[s->next_hs], c0, c1), __LINE__);
+                        s->a[s->next_hs], s->b[s->next_hs], c0, c1)); check_sweep(rc_, __LINE__); }
 }
 
 /* Part of a sweep: lattice 0 = main, 1 = half-step; local columns
@@ -209,13 +224,13 @@ void slb_solver_sweep_range(slb_solver *s, int lattice, int j_first, int j_last,
   if (j_last < part.j_last)   part.j_last = j_last;
   if (part.j_last < part.j_first) return;
   if (lattice == 0)
-    check_sweep(slb_sweep(&part, s->a0, s->a[s->current], s->b[s->current],
+    { int rc_; ON(s, rc_ = slb_sweep(&part, s->a0, s->a[s->current], s->b[s->current],
                           s->a[s->current_hs], s->b[s->current_hs],
-                          s->a[s->next], s->b[s->next], c0, c1), __LINE__);
+                          s->a[s->next], s->b[s->next], c0, c1)); check_sweep(rc_, __LINE__); }
   else
-    check_sweep(slb_sweep(&part, s->a0, s->a[s->current_hs], s->b[s->current_hs],
+    { int rc_; ON(s, rc_ = slb_sweep(&part, s->a0, s->a[s->current_hs], s->b[s->current_hs],
                           s->a[s->next], s->b[s->next],
-                          s->a[s->next_hs], s->b[s->next_hs], c0, c1), __LINE__);
+                          s->a[s->next_hs], s->b[s->next_hs], c0, c1)); check_sweep(rc_, __LINE__); }
 }
 
 void slb_solver_advance(slb_solver *s)
@@ -270,10 +285,9 @@ void slb_solver_step_fused_range(slb_solver *s, int j2_first, int j2_last, const
   if (g.j2_last < g.j2_first) return;
   g.j1_first = g.j2_first - 1 > j1_lo ? g.j2_first - 1 : j1_lo;
   g.j1_last  = g.j2_last + 1 < j1_hi ? g.j2_last + 1 : j1_hi;
-  check_sweep(slb_step_fused(&g, s->a0, s->a[s->current], s->b[s->current],
+  { int rc_; ON(s, rc_ = slb_step_fused(&g, s->a0, s->a[s->current], s->b[s->current],
                              s->a[s->current_hs], s->b[s->current_hs],
-                             s->a[s->next], s->b[s->next], s->a[s->next_hs], s->b[s->next_hs], c),
-              __LINE__);
+                             s->a[s->next], s->b[s->next], s->a[s->next_hs], s->b[s->next_hs], c)); check_sweep(rc_, __LINE__); }
 }
 
 /* one loop iteration as a single fused launch; same results as slb_solver_step */
@@ -297,7 +311,7 @@ static void sync_spares(slb_solver *s)
     HIP_OK(lattice_alloc(&s->spare_ah, bytes));
     HIP_OK(lattice_alloc(&s->spare_bh, bytes));
   }
-  hipStream_t st = (hipStream_t)slb_get_stream();
+  hipStream_t st = stream_of(s);
   HIP_OK(hipMemcpyAsync(s->spare_a,  s->a[s->current],    bytes, hipMemcpyDeviceToDevice, st));
   HIP_OK(hipMemcpyAsync(s->spare_b,  s->b[s->current],    bytes, hipMemcpyDeviceToDevice, st));
   HIP_OK(hipMemcpyAsync(s->spare_ah, s->a[s->current_hs], bytes, hipMemcpyDeviceToDevice, st));
@@ -347,11 +361,11 @@ void slb_solver_double_step_range_rows(slb_solver *s, int j_first, int j_last, c
     g.j_first[q] = g.j_first[q + 1] - 1 > lo[q] ? g.j_first[q + 1] - 1 : lo[q];
     g.j_last[q]  = g.j_last[q + 1] + 1 < hi[q] ? g.j_last[q + 1] + 1 : hi[q];
   }
-  check_sweep(slb_step_fused2_rows(&g, s->a0, s->a[s->current], s->b[s->current],
+  { int rc_; ON(s, rc_ = slb_step_fused2_rows(&g, s->a0, s->a[s->current], s->b[s->current],
                                    s->a[s->current_hs], s->b[s->current_hs],
                                    s->a[s->next], s->b[s->next], s->a[s->next_hs], s->b[s->next_hs],
                                    s->spare_a, s->spare_b, s->spare_ah, s->spare_bh, c,
-                                   rows_first, rows_second), __LINE__);
+                                   rows_first, rows_second)); check_sweep(rc_, __LINE__); }
 }
 
 /* after two iterations the ping-pong indices are back where they were; the
@@ -434,7 +448,7 @@ void slb_solver_multi_step_range(slb_solver *s, int S, int j_first, int j_last, 
     pa[q] = s->a[idx]; pb[q] = s->b[idx];
   }
   pa[Q - 2] = out[0]; pb[Q - 2] = out[1];
-  check_sweep(slb_step_multi(&g, s->a0, in, pa, pb, out, c), __LINE__);
+  { int rc_; ON(s, rc_ = slb_step_multi(&g, s->a0, in, pa, pb, out, c)); check_sweep(rc_, __LINE__); }
 }
 
 void slb_solver_multi_step_finish(slb_solver *s, int S)
@@ -469,7 +483,7 @@ void slb_solver_multi_step(slb_solver *s, int S)
 
 int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
 {
-  hipStream_t st = (hipStream_t)slb_get_stream();
+  hipStream_t st = stream_of(s);
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
@@ -510,7 +524,9 @@ int slb_solver_halo_pack(slb_solver *s, int which, int side, int ncols, float *b
   halo_arrays(s, which, &a, &b);
   if (ncols < 1 || ncols > s->G || !a) return -1;
   const int col = side == 0 ? s->G : s->G + s->W - ncols;       /* my outermost owned columns */
-  return slb_halo_pack(a, b, s->pitch, s->N + 1, col, ncols, buf);
+  int rc;
+  ON(s, rc = slb_halo_pack(a, b, s->pitch, s->N + 1, col, ncols, buf));
+  return rc;
 }
 
 int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const float *buf)
@@ -519,7 +535,9 @@ int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const 
   halo_arrays(s, which, &a, &b);
   if (ncols < 1 || ncols > s->G || !a) return -1;
   const int col = side == 0 ? s->G - ncols : s->G + s->W;       /* the ghost columns next to them */
-  return slb_halo_unpack(a, b, s->pitch, s->N + 1, col, ncols, buf);
+  int rc;
+  ON(s, rc = slb_halo_unpack(a, b, s->pitch, s->N + 1, col, ncols, buf));
+  return rc;
 }
 
 /* After a double step's edge ranges: the outermost owned columns of the new main lattice
@@ -548,7 +566,9 @@ static int halo_double(slb_solver *s, float *buf_left, float *buf_right, int pac
     }
   }
   if (k == 0) return 0;
-  return pack ? slb_halo_pack_segs(seg, k, s->pitch, nrows) : slb_halo_unpack_segs(seg, k, s->pitch, nrows);
+  int rc;
+  ON(s, rc = pack ? slb_halo_pack_segs(seg, k, s->pitch, nrows) : slb_halo_unpack_segs(seg, k, s->pitch, nrows));
+  return rc;
 }
 
 int slb_solver_halo_pack_double(slb_solver *s, float *buf_left, float *buf_right)
@@ -566,7 +586,9 @@ int slb_solver_halo_unpack_double(slb_solver *s, float *buf_left, float *buf_rig
  * doubles on the device, to be added across slabs and given to slb_av_update() */
 int slb_solver_av_partial(slb_solver *s, double *sums)
 {
-  return slb_av_partial(&s->av_slab, s->a[s->current], s->b[s->current], sums);
+  int rc;
+  ON(s, rc = slb_av_partial(&s->av_slab, s->a[s->current], s->b[s->current], sums));
+  return rc;
 }
 
 /* the rows av() reads of the CURRENT main lattice (a rows 0 and 1, b row 1) copied into a
@@ -575,7 +597,7 @@ int slb_solver_av_partial(slb_solver *s, double *sums)
 int slb_solver_copy_av_rows(slb_solver *s, float *rows)
 {
   const size_t row_bytes = sizeof(float) * (size_t)s->pitch;
-  hipStream_t st = (hipStream_t)slb_get_stream();
+  hipStream_t st = stream_of(s);
   hipError_t e = hipMemcpyAsync(rows, s->a[s->current], 2 * row_bytes, hipMemcpyDeviceToDevice, st);
   if (e == hipSuccess)
     e = hipMemcpyAsync(rows + 2 * (size_t)s->pitch, s->b[s->current] + s->pitch, row_bytes,
@@ -607,10 +629,11 @@ int slb_solver_frame_values_device(slb_solver *s, int source, const float *phi_x
   HIP_OK(hipMalloc((void **)&d_tab, tab_bytes));
   HIP_OK(hipMemcpy(d_tab, tab, tab_bytes, hipMemcpyHostToDevice));
   free(tab);
-  const int rc = source == 1
+  int rc;
+  ON(s, rc = source == 1
       ? slb_frame_values(s->a0, NULL, s->pitch, nrows, col_first, ncols, d_tab, nphi, d_out)
-      : slb_frame_values(s->a[s->current], s->b[s->current], s->pitch, nrows, col_first, ncols, d_tab, nphi, d_out);
-  if (rc == 0) HIP_OK(hipStreamSynchronize((hipStream_t)slb_get_stream()));
+      : slb_frame_values(s->a[s->current], s->b[s->current], s->pitch, nrows, col_first, ncols, d_tab, nphi, d_out));
+  if (rc == 0) HIP_OK(hipStreamSynchronize(stream_of(s)));
   HIP_OK(hipFree(d_tab));
   return rc;
 }
