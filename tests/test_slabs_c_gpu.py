@@ -161,3 +161,37 @@ def test_rccl_link_moves_a_message_on_this_gpu(slb):
             torch.cuda.synchronize()
     finally:
         L.slb_link_close(link)
+
+
+def test_python_wrapper_of_the_c_loop_steps_like_the_engine(slb, oracle):
+    """dist.CSlabRun (what bench.py drives at N > 1) with one rank: tiptoe, double steps and a
+    last step leave the oracle's lattices, and torch's current stream is the loop's main stream."""
+    import importlib
+    import torch
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")
+    drv = importlib.import_module(slb.__name__ + ".dist")
+    N, M = 10, 2999
+    p = oracle.make_params(N=N, M=M, B=0.6, omega=20.0)
+    slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    orc = oracle.OracleState(p)
+    run = drv.CSlabRun(slb, 0, 1)
+    try:
+        assert run.ranks_seen() == 1
+        assert torch.cuda.current_stream().cuda_stream == slb.lib().slb_slabs_main_stream(run.r)
+        run.tiptoe()
+        for _ in range(4):
+            run.double_step()
+        run.last_step()
+        orc.step(9)
+        torch.cuda.synchronize()
+        s = run.s
+        total = np.empty((N + 1, M + 3), np.float32)
+        for which, arr, idx in (("a", 1 + s.current, orc.st.current), ("b", 5 + s.current, orc.st.current),
+                                ("a", 1 + s.current_hs, orc.st.current_hs), ("b", 5 + s.current_hs, orc.st.current_hs)):
+            slb.lib().slb_slabs_gather_rows(run.r, arr, 0, N + 1, total.ctypes.data)
+            assert np.array_equal(total.view(np.uint32), orc.array(which, idx).view(np.uint32)), which
+    finally:
+        run.close()
+        orc.close()
