@@ -261,14 +261,15 @@ __device__ __forceinline__ void st4(float *base, unsigned off, const float (&r)[
 {
   float4 *q = reinterpret_cast<float4 *>(base + off);
   if constexpr (NT) {
-    __builtin_nontemporal_store(r[0], &q->x); __builtin_nontemporal_store(r[1], &q->y);
-    __builtin_nontemporal_store(r[2], &q->z); __builtin_nontemporal_store(r[3], &q->w);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = {r[0], r[1], r[2], r[3]};
+    __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(q));
   } else {
     *q = make_float4(r[0], r[1], r[2], r[3]);
   }
 }
 
-template <bool NT>
+template <bool NT, bool NTS = NT>
 __global__ void __launch_bounds__(256)
 sweep_pipe_kernel(const SweepArgs p)
 {
@@ -339,8 +340,8 @@ sweep_pipe_kernel(const SweepArgs p)
     const size_t row = (size_t)n * P;
     float *ao = p.a_out + row, *bo = p.b_out + row;
     if (wr_all) {
-      st4<NT>(ao, j, an);
-      if (n > 0) st4<NT>(bo, j, bn);
+      st4<NTS>(ao, j, an);
+      if (n > 0) st4<NTS>(bo, j, bn);
     } else {
 #pragma unroll
       for (int k = 0; k < V; k++) {
@@ -423,7 +424,7 @@ __device__ __forceinline__ void point_update_sel(
   }
 }
 
-template <bool NT, int MINW, bool DIAG = false>
+template <bool NT, int MINW, bool DIAG = false, bool NTS = NT>
 __global__ void __launch_bounds__(256, MINW)
 fused_step_kernel(const FusedArgs p)
 {
@@ -521,8 +522,8 @@ fused_step_kernel(const FusedArgs p)
       }
       if (r >= n0 && r < n1) {
         if (w1_all) {
-          st4<NT>(p.a_n + row, j, o1A);
-          if (r > 0) st4<NT>(p.b_n + row, j, o1B);
+          st4<NTS>(p.a_n + row, j, o1A);
+          if (r > 0) st4<NTS>(p.b_n + row, j, o1B);
         } else {
 #pragma unroll
           for (int k = 0; k < V; k++) {
@@ -567,8 +568,8 @@ fused_step_kernel(const FusedArgs p)
                      e1a[k + 2], e1a[k], e1b[k + 2], e1b[k], d1A_pp[k], d1B_pp[k], o2A[k], o2B[k]);
       }
       if (w2_all) {
-        st4<NT>(p.a_hn + rown, j, o2A);
-        if (n > 0) st4<NT>(p.b_hn + rown, j, o2B);
+        st4<NTS>(p.a_hn + rown, j, o2A);
+        if (n > 0) st4<NTS>(p.b_hn + rown, j, o2B);
       } else {
 #pragma unroll
         for (int k = 0; k < V; k++) {
@@ -636,7 +637,12 @@ struct Fused2Args {
 // H: halo lanes per side of a wave (1 suffices for the three hand-offs; 4 puts the 56 interior
 // lanes' stores -- 896 bytes per row -- on 128-byte line boundaries, at the price of forming
 // 8 of 64 columns twice instead of 2)
-template <int MINW, bool DIAG = false, bool ROWS = false, int H = 1>
+// NTS: non-temporal stores.  The interior lanes of a wave store pieces (992 bytes at H = 1)
+// that do not line up with 128-byte lines, so every boundary between two waves leaves a line
+// in two pieces; marked non-temporal the pieces are written out 2-10 % faster (measured on
+// MI355X with this kernel and, without arithmetic, with scripts/membench.hip).  NTL: the same
+// mark on the loads -- slower, the halo lanes' re-reads then miss.
+template <int MINW, bool DIAG = false, bool ROWS = false, int H = 1, bool NTS = false, bool NTL = false>
 __global__ void __launch_bounds__(256, MINW)
 fused2_step_kernel(const Fused2Args p)
 {
@@ -704,8 +710,14 @@ fused2_step_kernel(const Fused2Args p)
   const size_t P = (size_t)p.pitch;
 
   auto load4 = [&](const float *base, size_t row, float (&v)[V]) {
-    const float4 q = *reinterpret_cast<const float4 *>(base + row + j);
-    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    if constexpr (NTL) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const f4 q = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(base + row + j));
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+      const float4 q = *reinterpret_cast<const float4 *>(base + row + j);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    }
   };
   // replace the columns a stage does not produce by the present contents of `pa`/`pb`
   auto keep_old = [&](const float *pa, const float *pb, size_t row, unsigned okbits,
@@ -812,8 +824,8 @@ fused2_step_kernel(const Fused2Args p)
       const size_t row = (size_t)rc * P;
       if (rc >= n0 && rc < n1) {
         if (wC_all) {
-          st4<false>(p.a_o + row, j, o3A);
-          if (rc > 0) st4<false>(p.b_o + row, j, o3B);
+          st4<NTS>(p.a_o + row, j, o3A);
+          if (rc > 0) st4<NTS>(p.b_o + row, j, o3B);
         } else {
 #pragma unroll
           for (int k = 0; k < V; k++) {
@@ -857,8 +869,8 @@ fused2_step_kernel(const Fused2Args p)
       stage(rd, s[6], s[7], a0_3, o2A_pp, o2B_pp, e3a, e3b, d3A_pp, d3B_pp, o4A, o4B);
       const size_t row = (size_t)rd * P;
       if (wD_all) {
-        st4<false>(p.a_ho + row, j, o4A);
-        if (rd > 0) st4<false>(p.b_ho + row, j, o4B);
+        st4<NTS>(p.a_ho + row, j, o4A);
+        if (rd > 0) st4<NTS>(p.b_ho + row, j, o4B);
       } else {
 #pragma unroll
         for (int k = 0; k < V; k++) {
@@ -1623,18 +1635,18 @@ int launch_sweep(SweepArgs &args, int block)
   return (int)hipGetLastError();
 }
 
-template <bool NT>
+template <bool NT, bool NTS = NT>
 int launch_pipe(SweepArgs &args, int block)
 {
   args.jj0 = args.j_first / 4 * 4;
   const int cols  = args.j_last + 1 - args.jj0;
   const int lanes = (cols + 3) / 4;
   dim3 grid((lanes + block - 1) / block, (args.N + args.n_chunk - 1) / args.n_chunk);
-  hipLaunchKernelGGL((sweep_pipe_kernel<NT>), grid, dim3(block), 0, launch_stream(), args);
+  hipLaunchKernelGGL((sweep_pipe_kernel<NT, NTS>), grid, dim3(block), 0, launch_stream(), args);
   return (int)hipGetLastError();
 }
 
-template <bool NT, int MINW, bool DIAG = false>
+template <bool NT, int MINW, bool DIAG = false, bool NTS = NT>
 int launch_fused(FusedArgs &args, int block)
 {
   const int lo = args.j1_first < args.j2_first ? args.j1_first : args.j2_first;
@@ -1644,7 +1656,7 @@ int launch_fused(FusedArgs &args, int block)
   const int waves = (hi + 1 - args.jj0 + per_wave - 1) / per_wave;
   const int wpb = block / 64;
   dim3 grid((waves + wpb - 1) / wpb, (args.N + args.n_chunk - 1) / args.n_chunk);
-  hipLaunchKernelGGL((fused_step_kernel<NT, MINW, DIAG>), grid, dim3(block), 0, launch_stream(), args);
+  hipLaunchKernelGGL((fused_step_kernel<NT, MINW, DIAG, NTS>), grid, dim3(block), 0, launch_stream(), args);
   return (int)hipGetLastError();
 }
 
@@ -1674,7 +1686,7 @@ int resident_workgroups(K kernel, int block)
 // their rows in one workgroup each -- such a workgroup reads every input row once and forms
 // no row twice -- and only the groups left over are cut into chunks (`tail_chunk` rows);
 // narrower lattices are cut into chunks of `tail_chunk` rows throughout.
-template <int MINW, bool DIAG = false, bool ROWS = false, int H = 1>
+template <int MINW, bool DIAG = false, bool ROWS = false, int H = 2, bool NTS = true, bool NTL = false>
 int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
 {
   int lo = args.jf[0], hi = args.jl[0];
@@ -1685,7 +1697,7 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
   const int wpb = block / 64;
   const int groups = (waves + wpb - 1) / wpb;
   auto chunks_of = [&](int len) { return (args.N + len - 1) / len; };
-  const int slots = n_chunk > 0 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS, H>, block);
+  const int slots = n_chunk > 0 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL>, block);
   // (measured on MI355X, 128 rows: with 11 rounds of workgroups -- 2^23 columns -- whole
   // groups first is 2 % faster than cutting every group; with 1.4 rounds -- 2^20 columns --
   // it is no faster although it moves 5 % fewer bytes, and at 512 rows 5 % slower: the
@@ -1706,7 +1718,7 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
     args.wg_begin[2] = args.wg_begin[1] + (groups - whole) * chunks_of(tail_chunk);
   }
   for (int k = args.n_phase; k < 3; k++) { args.g0[k] = 0; args.ng[k] = 1; args.len[k] = args.N; args.wg_begin[k + 1] = args.wg_begin[k]; }
-  hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS, H>), dim3(args.wg_begin[args.n_phase]), dim3(block), 0,
+  hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL>), dim3(args.wg_begin[args.n_phase]), dim3(block), 0,
                      launch_stream(), args);
   return (int)hipGetLastError();
 }
@@ -1832,6 +1844,7 @@ int slb_sweep(const slb_slab *slab,
     case 3:  return launch_sweep<4, 1>(s, block);
     case 4:  return launch_pipe<false>(s, block);
     case 5:  return launch_pipe<true>(s, block);
+    case 9:  return launch_pipe<false, true>(s, block);   // nontemporal stores only
     default:
       fprintf(stderr, "slb_sweep: unknown variant %d\n", variant);
       return -1;
@@ -1884,6 +1897,7 @@ int slb_step_fused(const slb_step_geom *g,
   switch (g_variant) {
     case 6:  return launch_fused<false, 4>(s, block);
     case 7:  return launch_fused<true, 4>(s, block);      // nontemporal accesses for data touched once
+    case 8:  return launch_fused<false, 4, false, true>(s, block);   // nontemporal stores only
 #ifdef SLB_TIMING_VARIANTS
     case 99: return launch_fused<false, 4, true>(s, block);   // arithmetic removed: memory floor, wrong results
 #endif
@@ -1960,15 +1974,21 @@ int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
   if (s.N >= 128) cap = (7 * s.N + 15) / 16;
   // (two rounds of workgroups rather than one: at n-harmonics 64, g-grid 2^18 chunks of 11-12
   // rows take 0.176-0.178 ms per launch, 16 rows 0.183, 22 rows 0.191, 32 rows 0.204)
-  const int tail_chunk = auto_chunk(s.N, hi - lo + 1, 248, block, cap, 1536);
+  const int tail_chunk = auto_chunk(s.N, hi - lo + 1, 240, block, cap, 1536);
   // tuning variant 26: every strip group cut into chunks, as for a narrow lattice
   int n_chunk = g_n_chunk > 0 ? g_n_chunk : (g_variant == 26 || s.N < 64 ? tail_chunk : 0);
   if (rows_first) return launch_fused2<3, false, true>(s, block, n_chunk, tail_chunk);
+  // default: two halo lanes per side (the 60 interior lanes' stores start on 64-byte boundaries),
+  // non-temporal stores, registers for 3 waves per SIMD.  The rest are tuning variants.
   switch (g_variant) {
-    case 21: return launch_fused2<2>(s, block, n_chunk, tail_chunk);   // register budget of 2, 3 (default), 4 waves per SIMD
-    case 25: return launch_fused2<4>(s, block, n_chunk, tail_chunk);
-    case 29: return launch_fused2<3, false, false, 2>(s, block, n_chunk, tail_chunk);   // two, four halo lanes per side
-    case 30: return launch_fused2<3, false, false, 4>(s, block, n_chunk, tail_chunk);
+    case 20: return launch_fused2<3, false, false, 1, false>(s, block, n_chunk, tail_chunk);  // one halo lane, plain stores
+    case 21: return launch_fused2<2, false, false, 1, false>(s, block, n_chunk, tail_chunk);  // register budget of 2, 4 waves per SIMD
+    case 25: return launch_fused2<4, false, false, 1, false>(s, block, n_chunk, tail_chunk);
+    case 27: return launch_fused2<3, false, false, 1, true>(s, block, n_chunk, tail_chunk);   // one halo lane
+    case 29: return launch_fused2<3, false, false, 2, false>(s, block, n_chunk, tail_chunk);  // plain stores
+    case 30: return launch_fused2<3, false, false, 4, false>(s, block, n_chunk, tail_chunk);  // four halo lanes, plain stores
+    case 23: return launch_fused2<3, false, false, 4, true>(s, block, n_chunk, tail_chunk);   // four halo lanes
+    case 24: return launch_fused2<3, false, false, 2, true, true>(s, block, n_chunk, tail_chunk);   // non-temporal loads too
 #ifdef SLB_TIMING_VARIANTS
     case 98: return launch_fused2<3, true>(s, block, n_chunk, tail_chunk);   // arithmetic removed: memory floor, wrong results
 #endif
