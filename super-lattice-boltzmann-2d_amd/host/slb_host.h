@@ -200,6 +200,17 @@ int   slb_frame_phi_x(float *phi, int max);
 void *slb_frame_begin(const char *name, float t);
 void  slb_frame_block(void *file, float phi_x, const float *vals);
 void  slb_frame_end(void *file, const float *a01, int pitch);
+/* the same for the display=9 strobe files (reference: src/boltzmann_solver.c:459-484; the
+ * running image holds M+1 floats per phi_x block) and the display=3 dump
+ * (reference: src/boltzmann_c_solver.c:219-234) */
+float *slb_strobe_image(void);
+void  slb_strobe_block(void *file, float *image, int p, float phi_x, const float *vals);
+void  slb_strobe_end(void *file, const float *a_row0, float t);
+void  slb_display3_block(void *file, float phi_x, const float *vals, const float *vals0);
+/* read-from=: one round of new parameters, read by the process that owns the input (0 = the
+ * run is over) and applied by every process of the run (reference: src/boltzmann_solver.c:384-393) */
+int   slb_read_new_parameters(float msg[7]);
+void  slb_apply_new_parameters(const float msg[7], float t, float *T, float *t0);
 
 /* ---- several GPUs: one process per phi_y slab (no counterpart in the reference) --------- */
 extern int ranks;                      /* ranks= of the command line: processes (GPUs) of the run */
@@ -246,9 +257,9 @@ void        slb_slabs_av_finish(slb_slabs *r, float av6[6]);
 void        slb_slabs_av_set(slb_slabs *r, const float av6[6]);
 float      *slb_slabs_av_data(slb_slabs *r);
 void        slb_slabs_gather_rows(slb_slabs *r, int arr, int row0, int nrows, float *dst);
-int         slb_slabs_write_frame(slb_slabs *r, const char *name, float t);   /* display=8 over slabs */
-/* the display=4 / display=8 / display=77 program over `nranks` processes, forked here (nothing may have touched a
- * GPU yet); parse_cmd() has run */
+int         slb_slabs_write_frame(slb_slabs *r, const char *name, float t);   /* a display=7 / display=8 frame over slabs */
+/* the program (every display mode, read-from=) over `nranks` processes, forked here (nothing may have
+ * touched a GPU yet); parse_cmd() has run */
 int         slb_slab_main(int nranks);
 
 /* the whole program behind main() */

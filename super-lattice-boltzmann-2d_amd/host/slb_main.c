@@ -204,19 +204,87 @@ void slb_frame_end(void *file, const float *a01, int pitch)
   fclose(f);
 }
 
+/* The display=9 strobe file and the display=3 dump in pieces, for the same kind of caller:
+ * block number p of the strobe file (this period's values added to row p of the running
+ * image `image`, M+1 floats per row), the strobe file's closing lines (a_row0 = row 0 of a),
+ * and one block of the display=3 dump (vals0 = the equilibrium distribution's values). */
+void slb_strobe_block(void *file, float *image, int p, float phi_x, const float *vals)
+{
+  line_strobe((FILE *)file, image, phi_x, p, vals, NULL, host_M + 1);
+}
+
+void slb_strobe_end(void *file, const float *a_row0, float t)
+{
+  FILE *f = (FILE *)file;
+  float norm = 0;
+  float dphi_over_2 = host_dPhi / 2.0;
+  for (int m = 1; m < host_M + 1; m++) norm += (a_row0[m] + a_row0[m]) * dphi_over_2;
+  norm *= 2 * SLB_PI * sqrt(host_alpha);
+  fprintf(f, "# norm=%0.20f\n", norm);
+  fprintf(f, "# t=%0.20f\n", t);
+  printf("# norm=%0.20f\n", norm);
+}
+
+void slb_display3_block(void *file, float phi_x, const float *vals, const float *vals0)
+{
+  line_display3((FILE *)file, NULL, phi_x, 0, vals, vals0, host_M + 1);
+}
+
 /* display=9 strobe file: this period's frame added to the running image
  * (reference: src/boltzmann_solver.c:459-484) */
 static int write_strobe(FILE *f, slb_solver *s, float *strobe, const float *a0row, float t)
 {
-  float norm = 0;
-  float dphi_over_2 = host_dPhi / 2.0;
-  for (int m = 1; m < host_M + 1; m++) norm += (a0row[m] + a0row[m]) * dphi_over_2;
-  norm *= 2 * SLB_PI * sqrt(host_alpha);
   if (for_each_frame_row(s, f, 0, line_strobe, strobe) != 0) return -1;
-  fprintf(f, "# norm=%0.20f\n", norm);
-  fprintf(f, "# t=%0.20f\n", t);
-  printf("# norm=%0.20f\n", norm);
+  slb_strobe_end(f, a0row, t);
   return 0;
+}
+
+/* the strobe image of display=9: one row of M+1 values per phi_x block, zeroed */
+float *slb_strobe_image(void)
+{
+  size_t size = 0;
+  for (float phi_x = -SLB_PI; phi_x < SLB_PI; phi_x += 0.01) size += (size_t)host_M + 1;
+  float *image = (float *)calloc(size, sizeof(float));
+  if (!image) fprintf(stderr, "ERROR: out of host memory for the strobe image\n");
+  return image;
+}
+
+/* read-from=: one round of new parameters (reference: src/boltzmann_solver.c:384-393).
+ * slb_read_new_parameters() is for the process that owns the input: it returns 0 when the
+ * run is over, else msg = the six host_* values to go on with and the timeout.  What a new
+ * value does is the reference host's by default -- load_data() re-reads the host_* values,
+ * but bdt = B dt / (4 dPhi) is only ever formed at start-up (:113), so a new B acts through
+ * the field term alone.  SLB_REPARAM=fixed forms the derived constants again;
+ * SLB_REPARAM=cpu does what the reference's CPU solver does
+ * (src/boltzmann_c_solver.c:270-280: nothing reads the new value, only the averaging
+ * window moves).  slb_apply_new_parameters() is for every process of the run: t is the loop
+ * time the last pass ended at. */
+int slb_read_new_parameters(float msg[7])
+{
+  const char *mode = getenv("SLB_REPARAM");
+  const float keep[6] = {host_E_dc, host_E_omega, host_omega, host_mu, host_alpha, host_B};
+  const float timeout = scan_for_new_parameters();
+  if (timeout < -900) return 0;
+  if (mode != NULL && strcmp(mode, "cpu") == 0) {
+    host_E_dc = keep[0]; host_E_omega = keep[1]; host_omega = keep[2];
+    host_mu = keep[3]; host_alpha = keep[4]; host_B = keep[5];
+  }
+  msg[0] = host_E_dc; msg[1] = host_E_omega; msg[2] = host_omega;
+  msg[3] = host_mu; msg[4] = host_alpha; msg[5] = host_B; msg[6] = timeout;
+  return 1;
+}
+
+void slb_apply_new_parameters(const float msg[7], float t, float *T, float *t0)
+{
+  const char *mode = getenv("SLB_REPARAM");
+  host_E_dc = msg[0]; host_E_omega = msg[1]; host_omega = msg[2];
+  host_mu = msg[3]; host_alpha = msg[4]; host_B = msg[5];
+  t_start = t + msg[6];
+  t_max = t_start + *T;                         /* the period of the field BEFORE the change, as in the reference */
+  *t0 = t + host_dt;
+  *T = host_omega > 0 ? (2 * SLB_PI / host_omega) : 0;
+  if (mode != NULL && strcmp(mode, "fixed") == 0) slb_derive_and_load();
+  else load_data();
 }
 
 /* av() beside the time loop.  The sums need three rows of the main lattice a step has
@@ -389,10 +457,7 @@ int slb_main(int argc, char **argv)
   float *strobe = NULL;
   if (display == 9) {                                          /* 101 periods, one strobe image each */
     t_max = t_start + 101 * T;
-    size_t size = 0;
-    for (float phi_x = -SLB_PI; phi_x < SLB_PI; phi_x += 0.01) size += (size_t)host_M + 1;
-    strobe = (float *)calloc(size, sizeof(float));
-    if (!strobe) { fprintf(stderr, "ERROR: out of host memory for the strobe image\n"); return EXIT_FAILURE; }
+    if (!(strobe = slb_strobe_image())) return EXIT_FAILURE;
   } else {
     t_max = t_start + T;
   }
@@ -565,28 +630,10 @@ int slb_main(int argc, char **argv)
 
     if (read_from == NULL) break;
 
-    /* new parameter from stdin, continue from the present state
-     * (reference: src/boltzmann_solver.c:384-393).  What the new value does is the
-     * reference host's by default -- load_data() re-reads the host_* values, but bdt =
-     * B dt / (4 dPhi) is only ever formed at start-up (:113), so a new B acts through the
-     * field term alone.  SLB_REPARAM=fixed forms the derived constants again;
-     * SLB_REPARAM=cpu does what the reference's CPU solver does
-     * (src/boltzmann_c_solver.c:270-280: nothing reads the new value, only the averaging
-     * window moves). */
-    const char *mode = getenv("SLB_REPARAM");
-    const float keep[6] = {host_E_dc, host_E_omega, host_omega, host_mu, host_alpha, host_B};
-    const float timeout = scan_for_new_parameters();
-    if (timeout < -900) break;
-    if (mode != NULL && strcmp(mode, "cpu") == 0) {
-      host_E_dc = keep[0]; host_E_omega = keep[1]; host_omega = keep[2];
-      host_mu = keep[3]; host_alpha = keep[4]; host_B = keep[5];
-    }
-    t_start = t + timeout;
-    t_max = t_start + T;
-    t0 = t + host_dt;
-    T = host_omega > 0 ? (2 * SLB_PI / host_omega) : 0;
-    if (mode != NULL && strcmp(mode, "fixed") == 0) slb_derive_and_load();
-    else load_data();
+    /* new parameter from stdin, continue from the present state */
+    float msg[7];
+    if (!slb_read_new_parameters(msg)) break;
+    slb_apply_new_parameters(msg, t, &T, &t0);
     HIP_OK(hipMemset(s->av_data, 0, 6 * sizeof(float)));
     if (quiet == 0) printf("# t_max = %0.20f\n", t_max);
   }

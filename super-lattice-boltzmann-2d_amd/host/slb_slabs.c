@@ -500,76 +500,138 @@ void slb_slabs_gather_rows(slb_slabs *r, int arr, int row0, int nrows, float *ds
   }
 }
 
-/* The display=8 frame of the current main lattice (reference: src/boltzmann_solver.c:334-346,
- * 487-507): every slab forms the values of its own columns on its GPU, a batch of phi_x
- * values at a time; rank 0 puts the rows together and writes the file. */
-int slb_slabs_write_frame(slb_slabs *r, const char *name, float t)
+/* The values f(phi_x, phi_y) of the current main lattice for every phi_x block of a frame
+ * (reference: src/boltzmann_solver.c:334-346, 487-507): every slab forms the values of its own
+ * columns on its GPU, a batch of phi_x values at a time; rank 0 puts the rows together and
+ * hands each block -- the M+1 values of columns 1..M+1, and with_a0 the equilibrium
+ * distribution's as well -- to `line` (p = number of the block). */
+typedef void (*frame_block_fn)(void *ctx, int p, float phi_x, const float *vals, const float *vals0);
+
+static void frame_blocks(slb_slabs *r, int with_a0, frame_block_fn line, void *ctx)
 {
   slb_solver *s = r->s;
   slb_slabs_join(r);
   HIP_OK(hipStreamSynchronize(r->main));
   HIP_OK(hipStreamSynchronize(r->side));
-  const int total = s->M + 3, m1 = s->M + 1;
+  const int m1 = s->M + 1, sets = with_a0 ? 2 : 1;
   float phis[1024];
   const int nphi = slb_frame_phi_x(phis, 1024);
-  if (nphi > 1024) return -1;
-  float *a01 = r->rank == 0 ? (float *)malloc(sizeof(float) * 2 * (size_t)total) : NULL;
-  slb_slabs_gather_rows(r, 1 + s->current, 0, 2, a01);
-  void *f = NULL;
-  if (r->rank == 0 && !(f = slb_frame_begin(name, t))) exit(EXIT_FAILURE);
+  if (nphi > 1024) { fprintf(stderr, "ERROR: more than 1024 phi_x blocks\n"); exit(EXIT_FAILURE); }
   int batch = (int)((16u << 20) / (unsigned)m1);
   batch = batch < 8 ? 8 : (batch > 640 ? 640 : batch);
   const int mine = s->main_slab.j_last - s->main_slab.j_first + 1;
   const int base = s->M / r->nranks, rem = s->M % r->nranks;
-  float *d_mine = NULL, *d_all = NULL, *h_all = NULL, *line = NULL;
+  float *d_mine = NULL, *d_all = NULL, *h_all = NULL, *line_v = NULL;
   HIP_OK(hipMalloc((void **)&d_mine, sizeof(float) * (size_t)batch * mine));
   if (r->rank == 0) {
     HIP_OK(hipMalloc((void **)&d_all, sizeof(float) * (size_t)batch * m1));
-    h_all = (float *)malloc(sizeof(float) * (size_t)batch * m1);
-    line = (float *)malloc(sizeof(float) * (size_t)m1);
+    h_all = (float *)malloc(sizeof(float) * (size_t)batch * m1 * sets);
+    line_v = (float *)malloc(sizeof(float) * (size_t)m1 * sets);
+    if (!h_all || !line_v) { fprintf(stderr, "ERROR: out of host memory for the frame\n"); exit(EXIT_FAILURE); }
   }
   on_stream(r->main);
   for (int p0 = 0; p0 < nphi; p0 += batch) {
     const int np = nphi - p0 < batch ? nphi - p0 : batch;
-    check(slb_solver_frame_values_device(s, 0, phis + p0, np, d_mine), "the frame values");
-    if (r->rank != 0) {
-      slb_link_begin(r->link);
-      slb_link_send(r->link, 0, d_mine, (size_t)np * mine, r->main);
-      slb_link_end(r->link, r->main);
-      HIP_OK(hipStreamSynchronize(r->main));
-      continue;
-    }
-    /* rank q's block: np rows of its own columns, at offset np * (columns of the ranks before it) */
-    HIP_OK(hipMemcpyAsync(d_all, d_mine, sizeof(float) * (size_t)np * mine, hipMemcpyDeviceToDevice, r->main));
-    size_t off = (size_t)np * mine;
-    for (int q = 1; q < r->nranks; q++) {
-      const int w = base + (q < rem ? 1 : 0) + (q == r->nranks - 1 ? 1 : 0);
-      slb_link_begin(r->link);
-      slb_link_recv(r->link, q, d_all + off, (size_t)np * w, r->main);
-      slb_link_end(r->link, r->main);
-      off += (size_t)np * w;
-    }
-    HIP_OK(hipStreamSynchronize(r->main));
-    HIP_OK(hipMemcpy(h_all, d_all, sizeof(float) * (size_t)np * m1, hipMemcpyDeviceToHost));
-    for (int p = 0; p < np; p++) {
-      size_t blk = 0;
-      int col = 0;
-      for (int q = 0; q < r->nranks; q++) {
-        const int w = q == 0 ? mine : base + (q < rem ? 1 : 0) + (q == r->nranks - 1 ? 1 : 0);
-        memcpy(line + col, h_all + blk + (size_t)p * w, sizeof(float) * (size_t)w);
-        blk += (size_t)np * w;
-        col += w;
+    for (int set = 0; set < sets; set++) {
+      check(slb_solver_frame_values_device(s, set, phis + p0, np, d_mine), "the frame values");
+      if (r->rank != 0) {
+        slb_link_begin(r->link);
+        slb_link_send(r->link, 0, d_mine, (size_t)np * mine, r->main);
+        slb_link_end(r->link, r->main);
+        HIP_OK(hipStreamSynchronize(r->main));
+        continue;
       }
-      slb_frame_block(f, phis[p0 + p], line);
+      /* rank q's block: np rows of its own columns, at offset np * (columns of the ranks before it) */
+      HIP_OK(hipMemcpyAsync(d_all, d_mine, sizeof(float) * (size_t)np * mine, hipMemcpyDeviceToDevice, r->main));
+      size_t off = (size_t)np * mine;
+      for (int q = 1; q < r->nranks; q++) {
+        const int w = base + (q < rem ? 1 : 0) + (q == r->nranks - 1 ? 1 : 0);
+        slb_link_begin(r->link);
+        slb_link_recv(r->link, q, d_all + off, (size_t)np * w, r->main);
+        slb_link_end(r->link, r->main);
+        off += (size_t)np * w;
+      }
+      HIP_OK(hipStreamSynchronize(r->main));
+      HIP_OK(hipMemcpy(h_all + (size_t)set * batch * m1, d_all, sizeof(float) * (size_t)np * m1, hipMemcpyDeviceToHost));
+    }
+    if (r->rank != 0) continue;
+    for (int p = 0; p < np; p++) {
+      for (int set = 0; set < sets; set++) {
+        const float *h = h_all + (size_t)set * batch * m1;
+        size_t blk = 0;
+        int col = 0;
+        for (int q = 0; q < r->nranks; q++) {
+          const int w = q == 0 ? mine : base + (q < rem ? 1 : 0) + (q == r->nranks - 1 ? 1 : 0);
+          memcpy(line_v + (size_t)set * m1 + col, h + blk + (size_t)p * w, sizeof(float) * (size_t)w);
+          blk += (size_t)np * w;
+          col += w;
+        }
+      }
+      line(ctx, p0 + p, phis[p0 + p], line_v, with_a0 ? line_v + m1 : NULL);
     }
   }
   if (r->rank == 0) {
-    slb_frame_end(f, a01, total);
-    free(a01); free(h_all); free(line);
+    free(h_all); free(line_v);
     HIP_OK(hipFree(d_all));
   }
   HIP_OK(hipFree(d_mine));
+}
+
+static void block_frame(void *ctx, int p, float phi_x, const float *vals, const float *vals0)
+{
+  (void)p; (void)vals0;
+  slb_frame_block(ctx, phi_x, vals);
+}
+
+/* a display=7 / display=8 frame file of the current main lattice */
+int slb_slabs_write_frame(slb_slabs *r, const char *name, float t)
+{
+  slb_solver *s = r->s;
+  const int total = s->M + 3;
+  float *a01 = r->rank == 0 ? (float *)malloc(sizeof(float) * 2 * (size_t)total) : NULL;
+  slb_slabs_gather_rows(r, 1 + s->current, 0, 2, a01);
+  void *f = NULL;
+  if (r->rank == 0 && !(f = slb_frame_begin(name, t))) exit(EXIT_FAILURE);
+  frame_blocks(r, 0, block_frame, f);
+  if (r->rank == 0) {
+    slb_frame_end(f, a01, total);
+    free(a01);
+  }
   return 0;
+}
+
+/* a display=9 strobe file: this period's frame added to the running image on rank 0
+ * (reference: src/boltzmann_solver.c:459-484) */
+struct strobe_ctx { FILE *f; float *image; };
+static void block_strobe(void *ctx, int p, float phi_x, const float *vals, const float *vals0)
+{
+  struct strobe_ctx *c = (struct strobe_ctx *)ctx;
+  (void)vals0;
+  slb_strobe_block(c->f, c->image, p, phi_x, vals);
+}
+
+static void write_strobe(slb_slabs *r, const char *name, float *image, float t)
+{
+  slb_solver *s = r->s;
+  float *a0row = r->rank == 0 ? (float *)malloc(sizeof(float) * ((size_t)s->M + 3)) : NULL;
+  slb_slabs_gather_rows(r, 1 + s->current, 0, 1, a0row);
+  struct strobe_ctx c = {NULL, image};
+  if (r->rank == 0) {
+    if (!(c.f = fopen(name, "w"))) { perror("ERROR"); exit(EXIT_FAILURE); }
+    printf("\nWriting strobe %s\n", name);
+  }
+  frame_blocks(r, 0, block_strobe, &c);
+  if (r->rank == 0) {
+    slb_strobe_end(c.f, a0row, t);
+    fclose(c.f);
+    free(a0row);
+  }
+}
+
+static void block_display3(void *ctx, int p, float phi_x, const float *vals, const float *vals0)
+{
+  (void)p;
+  slb_display3_block(ctx, phi_x, vals, vals0);
 }
 
 int slb_slabs_ranks_seen(slb_slabs *r) { return r->link ? slb_link_ranks_seen(r->link) : 1; }
@@ -594,17 +656,20 @@ void slb_slabs_destroy(slb_slabs *r)
   free(r);
 }
 
-/* ---- the program over slabs: display=4, display=8 and display=77 --------------------------
+/* ---- the program over slabs ----------------------------------------------------------------
  * One process per rank, forked before anything has touched a GPU.  Rank q takes device
  * `device` + q when the machine has that many, and the ranks talk over RCCL; with fewer
  * devices (a one-GPU box) the ranks share them and talk over sockets -- a rehearsal that
  * runs the same loop.  SLB_TRANSPORT=fds forces the sockets. */
 /* What follows the step taken at loop time t with this frame_time: 0 nothing, 1 only av(),
- * 2 a display=77 record.  Two steps of kind 0 or 1 may share a launch. */
+ * 2 a display=77 record, a display=7 frame or a display=9 strobe test.  Two steps of kind 0 or 1
+ * may share a launch. */
 static int step_kind(float t, float frame_time)
 {
   if (display == 77) return host_E_omega > 0 && frame_time >= 0.01 ? 2 : 0;
+  if (display == 7)  return frame_time >= 0.01 && t > frame_start ? 2 : 0;
   if (display == 8)  return 0;
+  if (display == 9 && t >= t_start) return 2;
   return host_E_omega > 0 && t >= t_start ? 1 : 0;
 }
 
@@ -618,7 +683,9 @@ static int rank_main(int rank, int nranks, const int *fds)
   HIP_OK(hipSetDevice(use_rccl ? device + rank : (device + rank) % ndev));
 
   float T = host_omega > 0 ? (2 * SLB_PI / host_omega) : 0;
-  t_max = t_start + T;
+  float *strobe = NULL;
+  t_max = display == 9 ? t_start + 101 * T : t_start + T;      /* display=9: 101 periods, one strobe image each */
+  if (display == 9 && rank == 0 && !(strobe = slb_strobe_image())) return EXIT_FAILURE;
   if (rank == 0 && quiet == 0) printf("# t_max = %0.20f\n", t_max);
   slb_derive_and_load();
 
@@ -646,84 +713,129 @@ static int rank_main(int rank, int nranks, const int *fds)
   slb_slabs_tiptoe(r);
 
   const int timing = getenv("SLB_TIMING") != NULL;
-  struct timespec w0, w1;
-  if (timing) { HIP_OK(hipDeviceSynchronize()); clock_gettime(CLOCK_MONOTONIC, &w0); }
-  long loop_steps = 0;
-  int progress = 0;
-  float t, frame_time = 0;
+  int progress = 0, frame_number = 1;
+  float t = 0, t0 = 0, frame_time = 0, last_tT_reminder = 0;
+  char file_name[64];
   const int total = host_M + 3;
   float *a012 = rank == 0 ? (float *)malloc(sizeof(float) * 3 * (size_t)total) : NULL;
   float *b12  = rank == 0 ? (float *)malloc(sizeof(float) * 2 * (size_t)total) : NULL;
-  for (t = 0; t < t_max; t += host_dt, loop_steps++) {
-    const int k1 = step_kind(t, frame_time);
-    const float t2 = t + host_dt, ft2 = frame_time + host_dt;
-    const int k2 = step_kind(t2, ft2);
-    s->t = t;                              /* the engine forms the cosines from its own clock */
-    if (t2 < t_max && k1 < 2 && k2 < 2) {
-      /* two iterations in one launch: same bits, the lattice in between is never stored
-       * (the rows av() reads of it are) */
-      if (k1 || k2) {
-        float *rows[2];
-        slb_slabs_av_rows(r, 2, rows);
-        slb_slabs_double_step(r, rows[0], rows[1]);
-        const float tt[2] = {k1 ? t : t2, t2};
-        slb_slabs_av_submit(r, k1 + k2, tt, k1 ? 0 : 1);
-      } else {
-        slb_slabs_double_step(r, NULL, NULL);
+  for (;;) {
+    struct timespec w0, w1;
+    long loop_steps = 0;
+    if (timing) { HIP_OK(hipDeviceSynchronize()); clock_gettime(CLOCK_MONOTONIC, &w0); }
+    for (t = t0; t < t_max; t += host_dt, loop_steps++) {
+      const int k1 = step_kind(t, frame_time);
+      const float t2 = t + host_dt, ft2 = frame_time + host_dt;
+      const int k2 = step_kind(t2, ft2);
+      s->t = t;                              /* the engine forms the cosines from its own clock */
+      if (t2 < t_max && k1 < 2 && k2 < 2) {
+        /* two iterations in one launch: same bits, the lattice in between is never stored
+         * (the rows av() reads of it are) */
+        if (k1 || k2) {
+          float *rows[2];
+          slb_slabs_av_rows(r, 2, rows);
+          slb_slabs_double_step(r, rows[0], rows[1]);
+          const float tt[2] = {k1 ? t : t2, t2};
+          slb_slabs_av_submit(r, k1 + k2, tt, k1 ? 0 : 1);
+        } else {
+          slb_slabs_double_step(r, NULL, NULL);
+        }
+        t = t2;
+        loop_steps++;
+        frame_time = ft2 + host_dt;
+        if (rank == 0 && out != stdout && display != 7 && quiet == 0 && (progress += 2) >= 300) {
+          printf("\rt=%0.9f %0.2f%%", t, t / t_max * 100);
+          fflush(stdout);
+          progress = 0;
+        }
+        continue;
       }
-      t = t2;
-      loop_steps++;
-      frame_time = ft2 + host_dt;
-      if (rank == 0 && out != stdout && quiet == 0 && (progress += 2) >= 300) {
+      /* the last iteration of the run lets nothing travel; with read-from= another pass may follow */
+      if (t2 < t_max || read_from != NULL) slb_slabs_step(r); else slb_slabs_last_step(r);
+      if (display == 77 && k1 == 2) {
+        /* a display=77 record: av() of the lattice this step wrote, the sums from the one
+         * before it (reference: src/boltzmann_c_solver.c:180-187, 298-331) */
+        float av6[6] = {0, 0, 0, 0, 0, 0};
+        slb_slabs_av_submit_current(r, t);
+        slb_slabs_av_finish(r, av6);
+        slb_slabs_gather_rows(r, 1 + s->next, 0, 3, a012);     /* after the swap `next` is the old lattice */
+        slb_slabs_gather_rows(r, 5 + s->next, 1, 2, b12);
+        if (rank == 0) {
+          const float norm = slb_host_norm(a012, host_M, host_dPhi, host_alpha);
+          slb_write_display77(norm, a012, b12, total, av6, t);
+        }
+        slb_slabs_av_set(r, av6);            /* the CPU solver rescales its averaging data in place */
+        frame_time = 0;
+      } else if (k1 == 1) {
+        slb_slabs_av_submit_current(r, t);     /* (display=9 prints no averages: its steps skip av()) */
+      }
+      if (display == 9 && t >= t_start) {
+        /* a strobe image whenever t/T wraps (reference: src/boltzmann_solver.c:260-275) */
+        float tT = t / T;
+        float tT_reminder = tT - ((int)tT);
+        if (tT_reminder < last_tT_reminder) {
+          sprintf(file_name, "strobe%08d.data", frame_number++);
+          write_strobe(r, file_name, strobe, t);
+          frame_time = 0;
+        }
+        last_tT_reminder = tT_reminder;
+      }
+      if (display == 7 && k1 == 2) {                                  /* a movie frame */
+        sprintf(file_name, "frame%08d.data", frame_number++);
+        slb_slabs_write_frame(r, file_name, t);
+        frame_time = 0;
+      }
+      if (rank == 0 && out != stdout && display != 7 && quiet == 0 && ++progress >= 300) {
         printf("\rt=%0.9f %0.2f%%", t, t / t_max * 100);
         fflush(stdout);
         progress = 0;
       }
-      continue;
+      frame_time += host_dt;
     }
-    if (t2 < t_max) slb_slabs_step(r); else slb_slabs_last_step(r);
-    if (k1 == 2) {
-      /* a display=77 record: av() of the lattice this step wrote, the sums from the one
-       * before it (reference: src/boltzmann_c_solver.c:180-187, 298-331) */
-      float av6[6] = {0, 0, 0, 0, 0, 0};
-      slb_slabs_av_submit_current(r, t);
-      slb_slabs_av_finish(r, av6);
-      slb_slabs_gather_rows(r, 1 + s->next, 0, 3, a012);     /* after the swap `next` is the old lattice */
-      slb_slabs_gather_rows(r, 5 + s->next, 1, 2, b12);
-      if (rank == 0) {
-        const float norm = slb_host_norm(a012, host_M, host_dPhi, host_alpha);
-        slb_write_display77(norm, a012, b12, total, av6, t);
-      }
-      slb_slabs_av_set(r, av6);            /* the CPU solver rescales its averaging data in place */
-      frame_time = 0;
-    } else if (k1 == 1) {
-      slb_slabs_av_submit_current(r, t);
+    float av6[6] = {0, 0, 0, 0, 0, 0};
+    slb_slabs_av_finish(r, av6);
+    if (timing) {
+      HIP_OK(hipDeviceSynchronize());
+      clock_gettime(CLOCK_MONOTONIC, &w1);
+      const double sec = (double)(w1.tv_sec - w0.tv_sec) + 1e-9 * (double)(w1.tv_nsec - w0.tv_nsec);
+      if (rank == 0)
+        fprintf(stderr, "# time loop: %ld iterations in %.4f s (%.4f ms each)\n", loop_steps, sec,
+                loop_steps ? 1e3 * sec / loop_steps : 0.0);
     }
-    frame_time += host_dt;
-  }
-  float av6[6] = {0, 0, 0, 0, 0, 0};
-  slb_slabs_av_finish(r, av6);
-  if (timing) {
-    HIP_OK(hipDeviceSynchronize());
-    clock_gettime(CLOCK_MONOTONIC, &w1);
-    const double sec = (double)(w1.tv_sec - w0.tv_sec) + 1e-9 * (double)(w1.tv_nsec - w0.tv_nsec);
-    if (rank == 0)
-      fprintf(stderr, "# time loop: %ld iterations in %.4f s (%.4f ms each)\n", loop_steps, sec,
-              loop_steps ? 1e3 * sec / loop_steps : 0.0);
-  }
 
-  if (display == 4) {
-    /* the display=4 record from the three rows its sums read, put together on rank 0 */
+    /* the three rows the closing sums read, put together on rank 0 */
     slb_slabs_gather_rows(r, 1 + s->current, 0, 2, a012);
     slb_slabs_gather_rows(r, 5 + s->current, 1, 1, b12);
-    if (rank == 0) {
-      const float norm = slb_host_norm(a012, host_M, host_dPhi, host_alpha);
-      slb_write_display4(norm, a012, b12, total, av6, T);
+    const float norm = rank == 0 ? slb_host_norm(a012, host_M, host_dPhi, host_alpha) : 0;
+    if (display == 3) {
+      /* the final distribution next to the equilibrium one
+       * (reference: src/boltzmann_c_solver.c:219-234) */
+      frame_blocks(r, 1, block_display3, out);
+      if (rank == 0) {
+        fprintf(out, "# norm=%0.20f\n", norm);
+        printf("# norm=%0.20f\n", norm);
+      }
+      break;
     }
+    if (display == 8) { slb_slabs_write_frame(r, "frame.data", t); break; }
+    if (display == 4 && rank == 0) slb_write_display4(norm, a012, b12, total, av6, T);
+    if (read_from == NULL) break;
+
+    /* new parameters: rank 0 owns the input and tells the others (over the start-up sockets) */
+    float msg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (rank == 0) {
+      msg[7] = (float)slb_read_new_parameters(msg);
+      for (int q = 1; q < nranks; q++)
+        if (write(fds[q], msg, sizeof(msg)) != (ssize_t)sizeof(msg)) { perror("ERROR"); return EXIT_FAILURE; }
+    } else if (read(fds[0], msg, sizeof(msg)) != (ssize_t)sizeof(msg)) { perror("ERROR"); return EXIT_FAILURE; }
+    if (msg[7] == 0) break;
+    slb_apply_new_parameters(msg, t, &T, &t0);
+    const float zero6[6] = {0, 0, 0, 0, 0, 0};
+    slb_slabs_av_set(r, zero6);
+    if (rank == 0 && quiet == 0) printf("# t_max = %0.20f\n", t_max);
   }
-  if (display == 8) slb_slabs_write_frame(r, "frame.data", t);
   if (rank == 0) slb_close_output();
-  free(a012); free(b12);
+  free(a012); free(b12); free(strobe);
   slb_slabs_destroy(r);
   slb_link_close(link);
   return EXIT_SUCCESS;
@@ -731,15 +843,7 @@ static int rank_main(int rank, int nranks, const int *fds)
 
 int slb_slab_main(int nranks)
 {
-  if (display != 4 && display != 77 && display != 8) {
-    fprintf(stderr, "ERROR: with ranks= the program writes display=4 records, display=8 frames and display=77 traces only.\n");
-    return EXIT_FAILURE;
-  }
   if (display == 77 && host_N < 2) { fprintf(stderr, "ERROR: display=77 needs n-harmonics >= 2.\n"); return EXIT_FAILURE; }
-  if (read_from != NULL) {
-    fprintf(stderr, "ERROR: read-from= is not available with ranks=.\n");
-    return EXIT_FAILURE;
-  }
   if (nranks < 1 || nranks > 64) { fprintf(stderr, "ERROR: Invalid value of ranks= parameter.\n"); return EXIT_FAILURE; }
   if (nranks == 1) return rank_main(0, 1, NULL);
   /* a socket for every pair of ranks: start-up data, and the messages themselves when the

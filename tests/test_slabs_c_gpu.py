@@ -72,14 +72,76 @@ def test_program_over_ranks_writes_the_single_gpu_frame(ranks, grid, tmp_path, s
     assert [l for l in one.stdout.splitlines() if "norm" in l] == [l for l in many.stdout.splitlines() if "norm" in l]
 
 
-def test_program_over_ranks_refuses_what_it_does_not_do(tmp_path, solver_bin):
+def _one_and_many(solver_bin, tmp_path, args, ranks, stdin_text=None, env=None):
+    (tmp_path / "one").mkdir(), (tmp_path / "many").mkdir()
+    env = None if env is None else {**os.environ, **env}
+    one = subprocess.run([solver_bin] + args, cwd=tmp_path / "one", capture_output=True, text=True, timeout=300,
+                         input=stdin_text, env=env)
+    assert one.returncode == 0, one.stdout + one.stderr
+    many = subprocess.run([solver_bin] + args + [f"ranks={ranks}"], cwd=tmp_path / "many", capture_output=True,
+                          text=True, timeout=300, input=stdin_text, env=env)
+    assert many.returncode == 0, many.stdout + many.stderr
+    return one, many
+
+
+MODES = ["E_dc=1", "E_omega=0.1", "mu=5", "alpha=1", "PhiYmin=-4", "PhiYmax=4", "dt=0.001", "quiet=1", "o=out.txt"]
+
+
+@pytest.mark.parametrize("ranks,grid", [(2, "37"), (3, "500")])
+def test_program_over_ranks_writes_the_single_gpu_movie(ranks, grid, tmp_path, solver_bin):
+    """display=7 over ranks: a frame file every 0.01 of time once t > frame-start (single steps
+    with a ghost refresh where a frame follows, double steps in between), same names, same bytes."""
+    args = ["display=7", "omega=100", "B=0.5", "n-harmonics=6", "g-grid=" + grid, "t-max=0.02", "frame-start=0.03"] + MODES
+    one, many = _one_and_many(solver_bin, tmp_path, args, ranks)
+    names = sorted(f.name for f in (tmp_path / "one").glob("frame*.data"))
+    assert names == sorted(f.name for f in (tmp_path / "many").glob("frame*.data")) and len(names) >= 4
+    for n in names:
+        assert (tmp_path / "one" / n).read_bytes() == (tmp_path / "many" / n).read_bytes(), n
+    pick = lambda s: [l for l in s.splitlines() if l.startswith("Writing") or "norm" in l]
+    assert pick(one.stdout) == pick(many.stdout)
+
+
+def test_program_over_ranks_writes_the_single_gpu_strobes(tmp_path, solver_bin):
+    """display=9 over ranks: 101 periods, the strobe image accumulated on rank 0."""
+    args = ["display=9", "omega=400", "B=0.5", "n-harmonics=4", "g-grid=29", "t-max=0.01"] + MODES
+    one, many = _one_and_many(solver_bin, tmp_path, args, 2)
+    names = sorted(f.name for f in (tmp_path / "one").glob("strobe*.data"))
+    assert names == sorted(f.name for f in (tmp_path / "many").glob("strobe*.data")) and len(names) == 101
+    for n in (names[0], names[1], names[50], names[-1]):
+        assert (tmp_path / "one" / n).read_bytes() == (tmp_path / "many" / n).read_bytes(), n
+
+
+@pytest.mark.parametrize("ranks,grid", [(2, "61"), (4, "1000")])
+def test_program_over_ranks_writes_the_single_gpu_dump(ranks, grid, tmp_path, solver_bin):
+    """display=3 over ranks: the final distribution next to the equilibrium one, and the norm."""
+    args = ["display=3", "omega=100", "B=0.5", "n-harmonics=8", "g-grid=" + grid, "t-max=0.01"] + MODES
+    one, many = _one_and_many(solver_bin, tmp_path, args, ranks)
+    a, b = (tmp_path / "one" / "out.txt").read_bytes(), (tmp_path / "many" / "out.txt").read_bytes()
+    assert len(a.splitlines()) == 629 * (int(grid) - 1) + 1 and a == b
+    assert [l for l in one.stdout.splitlines() if "norm" in l] == [l for l in many.stdout.splitlines() if "norm" in l]
+
+
+@pytest.mark.parametrize("mode", [None, "cpu", "fixed"])
+def test_program_over_ranks_goes_on_with_new_parameters(mode, tmp_path, solver_bin):
+    """read-from=stdin over ranks: rank 0 reads the new value and tells the others; every
+    record equals the single-GPU program's in each reading of what a new value does."""
+    args = ["display=4", "omega=100", "B=0.5", "n-harmonics=8", "g-grid=1001", "t-max=0.02", "read-from=stdin"] + MODES
+    records = "E_dc 1.5 0.02\nB 0.4 0.013\nomega 50 0.01\nbogus 1 0.005\nexit\n"
+    one, many = _one_and_many(solver_bin, tmp_path, args, 3, stdin_text=records,
+                              env=None if mode is None else {"SLB_REPARAM": mode})
+    a, b = (tmp_path / "one" / "out.txt").read_text(), (tmp_path / "many" / "out.txt").read_text()
+    assert len(a.splitlines()) == 15 and a == b
+
+
+def test_program_over_ranks_refuses_what_it_cannot_do(tmp_path, solver_bin):
     args = ["E_dc=1", "E_omega=0.1", "mu=5", "alpha=1", "PhiYmin=-4", "PhiYmax=4", "omega=100", "B=0.5",
-            "n-harmonics=8", "g-grid=500", "t-max=0.01", "o=stdout", "ranks=2"]
-    r = subprocess.run([solver_bin, "display=7"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=60)
-    assert r.returncode == 1 and "display=4 records, display=8 frames and display=77 traces only" in r.stderr
-    r = subprocess.run([solver_bin, "display=4"] + args[:-1] + ["ranks=0"], cwd=tmp_path, capture_output=True,
+            "n-harmonics=8", "g-grid=500", "t-max=0.01", "o=stdout"]
+    r = subprocess.run([solver_bin, "display=4"] + args + ["ranks=0"], cwd=tmp_path, capture_output=True,
                        text=True, timeout=60)
     assert r.returncode == 1 and "Invalid value of ranks=" in r.stderr
+    r = subprocess.run([solver_bin, "display=77", "ranks=2"] + [a for a in args if not a.startswith("n-harm")] +
+                       ["n-harmonics=1"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "display=77 needs n-harmonics >= 2" in r.stderr
 
 
 def test_single_rank_loop_in_c_matches_the_oracle(slb, oracle):
