@@ -39,6 +39,7 @@ launches and moves 2*ncols*(N+1) floats per side.
 """
 import collections
 import contextlib
+import os
 import ctypes as C
 
 import torch
@@ -235,8 +236,8 @@ class SlabRun:
         if isinstance(self.eng, HipEngine) and (self.left is not None or self.right is not None):
             self.main = torch.cuda.current_stream()
             # default priority: a high-priority side stream was seen to stall runs in which
-            # several processes share one GPU (its event waits then starve the main streams)
-            self.side = torch.cuda.Stream()
+            # several processes share one GPU (SLB_SIDE_PRIORITY=-1 asks for one, to look into it)
+            self.side = torch.cuda.Stream(priority=int(os.environ.get("SLB_SIDE_PRIORITY", "0")))
             self.ev_main = torch.cuda.Event()       # the last interior launch
             self.ev_side = torch.cuda.Event()       # the last halo chain
             self.side_busy = False
