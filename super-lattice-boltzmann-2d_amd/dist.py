@@ -385,13 +385,13 @@ class SlabRun:
     @contextlib.contextmanager
     def _on_side(self):
         """Launches of the engine and of torch.distributed go to the side stream."""
-        set_stream = self.eng.slb.lib().slb_set_stream
+        L = self.eng.slb.lib()
         with torch.cuda.stream(self.side):
-            set_stream(self.side.cuda_stream)
+            L.slb_push_stream(self.side.cuda_stream)     # the calling thread's launches, for the duration
             try:
                 yield
             finally:
-                set_stream(self.main.cuda_stream)
+                L.slb_pop_stream()
 
     def _double_step_two_streams(self, kw):
         e = self.eng
