@@ -1702,7 +1702,8 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
   // groups first is 2 % faster than cutting every group; with 1.4 rounds -- 2^20 columns --
   // it is no faster although it moves 5 % fewer bytes, and at 512 rows 5 % slower: the
   // leftover groups then start late and run at a fraction of the device's bandwidth)
-  const int whole = slots > 0 && groups >= 4 * slots ? groups / slots * slots : 0;
+  const int min_rounds = g_variant == 32 ? 1 : 4;        // tuning variant 32: whole strips first on any lattice
+  const int whole = slots > 0 && groups >= min_rounds * slots ? groups / slots * slots : 0;
   if (n_chunk <= 0 && whole == 0) n_chunk = tail_chunk;
   if (n_chunk > 0) {
     if (n_chunk > args.N) n_chunk = args.N;
