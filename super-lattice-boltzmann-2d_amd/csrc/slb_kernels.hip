@@ -1681,11 +1681,12 @@ int resident_workgroups(K kernel, int block)
 }
 
 // n_chunk > 0: every strip group is cut into chunks of n_chunk rows (one phase).
-// n_chunk == 0 (the library chooses): on a lattice wide enough for many rounds of
-// workgroups, as many strip groups as fill the device a whole number of times take all
-// their rows in one workgroup each -- such a workgroup reads every input row once and forms
-// no row twice -- and only the groups left over are cut into chunks (`tail_chunk` rows);
-// narrower lattices are cut into chunks of `tail_chunk` rows throughout.
+// n_chunk == 0 (the library chooses): on a lattice of at least one round of workgroups, as
+// many strip groups as fill the device a whole number of times take all their rows in one
+// workgroup each -- such a workgroup reads every input row once and forms no row twice --
+// and only the groups left over are cut into chunks (`tail_chunk` rows, or shorter ones when
+// the lattice has few rounds); narrower lattices are cut into chunks of `tail_chunk` rows
+// throughout.
 template <int MINW, bool DIAG = false, bool ROWS = false, int H = 2, bool NTS = true, bool NTL = false>
 int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
 {
@@ -1698,12 +1699,21 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
   const int groups = (waves + wpb - 1) / wpb;
   auto chunks_of = [&](int len) { return (args.N + len - 1) / len; };
   const int slots = n_chunk > 0 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL>, block);
-  // (measured on MI355X, 128 rows: with 11 rounds of workgroups -- 2^23 columns -- whole
-  // groups first is 2 % faster than cutting every group; with 1.4 rounds -- 2^20 columns --
-  // it is no faster although it moves 5 % fewer bytes, and at 512 rows 5 % slower: the
-  // leftover groups then start late and run at a fraction of the device's bandwidth)
-  const int min_rounds = g_variant == 32 ? 1 : 4;        // tuning variant 32: whole strips first on any lattice
+  // (measured on MI355X with two halo lanes and non-temporal stores: whole groups first wins
+  // from one round of workgroups up -- 2.02 against 2.11 ms at 128 rows x 2^21 columns, 2.06
+  // against 2.15 at 256 x 2^20, 0.53 against 0.57 at 64 x 2^20, 1.02-1.04 against 1.03-1.08 at
+  // 128 x 2^20 -- provided the strips left over are cut finely enough to fill the device)
+  // (tuning variant 34: the earlier rule -- below four rounds of workgroups every strip is cut)
+  const int min_rounds = g_variant == 34 ? 4 : 1;
   const int whole = slots > 0 && groups >= min_rounds * slots ? groups / slots * slots : 0;
+  if (whole > 0 && whole < groups && groups < 4 * slots && g_variant != 34) {
+    // few rounds: the strips left over are cut into as many chunks as make their workgroups
+    // fill the device once, three at least
+    int c = (slots + (groups - whole) - 1) / (groups - whole);
+    c = c < 3 ? 3 : c;
+    tail_chunk = (args.N + c - 1) / c;
+    if (tail_chunk < 8) tail_chunk = args.N < 8 ? args.N : 8;
+  }
   if (n_chunk <= 0 && whole == 0) n_chunk = tail_chunk;
   if (n_chunk > 0) {
     if (n_chunk > args.N) n_chunk = args.N;
@@ -1975,7 +1985,7 @@ int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
   if (s.N >= 128) cap = (7 * s.N + 15) / 16;
   // (two rounds of workgroups rather than one: at n-harmonics 64, g-grid 2^18 chunks of 11-12
   // rows take 0.176-0.178 ms per launch, 16 rows 0.183, 22 rows 0.191, 32 rows 0.204)
-  const int tail_chunk = auto_chunk(s.N, hi - lo + 1, 240, block, cap, 1536);
+  int tail_chunk = auto_chunk(s.N, hi - lo + 1, 240, block, cap, 1536);
   // tuning variant 26: every strip group cut into chunks, as for a narrow lattice
   int n_chunk = g_n_chunk > 0 ? g_n_chunk : (g_variant == 26 || s.N < 64 ? tail_chunk : 0);
   if (rows_first) return launch_fused2<3, false, true>(s, block, n_chunk, tail_chunk);

@@ -313,7 +313,7 @@ def test_double_step_bit_exact(slb, oracle, N, M, B, omega, pairs, n_chunk):
     L = slb.lib()
     try:
         sol.tiptoe()
-        for variant in (0, 20, 21, 23, 24, 25, 26, 27, 29, 30):
+        for variant in (0, 20, 21, 23, 24, 25, 26, 27, 29, 30, 34):
             L.slb_set_tuning(variant, n_chunk, 0)
             for _ in range(pairs):
                 sol.double_step()
