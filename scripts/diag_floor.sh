@@ -2,7 +2,7 @@
 # with -DSLB_TIMING_VARIANTS) next to the real kernel, for the launch schedules; then SQ
 # counters and the busy-cycle count of the real kernel (clock = GRBM_GUI_ACTIVE / duration).
 O=$PWD/gpurun_out/${1:-diag}; mkdir -p $O; R=$PWD
-SLB_LIB=$R/ab/libslb2d_diag.so timeout -k 10 200 python scripts/tune.py --double --variants 0,98,27,20 --chunks 0,56,32 --blocks 256 --steps 40 > $O/floor.txt 2>&1 || exit 1
+SLB_LIB=$R/ab/libslb2d_diag.so timeout -k 10 200 python scripts/tune.py --double --variants 0,98,0,98,0,98 --chunks 0 --blocks 256 --steps 40 > $O/floor.txt 2>&1 || exit 1
 cd /tmp; export TMPDIR=/tmp
 timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_sq -o sq -- python3 $R/bench.py --no-cpu --no-two-sweep --steps 10 --warmup 2 --repeats 1 > $O/pmc_sq.log 2>&1 || exit 1
 cd $R; cat $O/floor.txt
