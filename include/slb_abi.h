@@ -314,10 +314,17 @@ void  slb_pop_stream(void);
  *   lane with neighbour columns re-read through L1, 3 = neighbour columns from
  *   the adjacent lanes, 4 = software-pipelined form of 2, 5 = 4 with nontemporal
  *   accesses for data touched once (the default where rows are 16-byte aligned).
- * variant, slb_step_fused: 6 = plain accesses (default), 7 = nontemporal.
- * variant, slb_step_fused2: 21 / 23 (default) / 25 = register budget of 2 / 3 / 4
- *   waves per SIMD.  slb_step_multi: 32 / 33 / 34 = two columns per lane instead
- *   of four, with a register budget of 2 / 3 / 4 waves per SIMD.
+ *   9 = 4 with nontemporal stores only.
+ * variant, slb_step_fused: 6 = plain accesses (default), 7 = nontemporal, 8 =
+ *   nontemporal stores only.
+ * variant, slb_step_fused2 (default: two halo lanes per side of a wave, nontemporal
+ *   stores, registers for 3 waves per SIMD, whole column strips first from one round
+ *   of workgroups up): 20 = one halo lane and plain stores, 21 / 25 = 20 with a
+ *   register budget of 2 / 4 waves per SIMD, 27 / 23 = one / four halo lanes, 29 / 30
+ *   = two / four halo lanes with plain stores, 24 = nontemporal loads too, 26 = every
+ *   strip cut into chunks of rows, 34 = every strip cut below four rounds of workgroups.
+ *   slb_step_multi: 32 / 33 / 34 = two columns per lane instead of four, with a
+ *   register budget of 2 / 3 / 4 waves per SIMD.
  *   slb_seq_sum: 41..47 = other workgroup shapes.
  * n_chunk = rows per workgroup in n (0: by lattice width), block = threads (0: 256). */
 void slb_set_tuning(int variant, int n_chunk, int block);
