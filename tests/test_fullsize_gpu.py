@@ -78,7 +78,7 @@ def _rows_to_compare(N, M):
     if (N + 1) * M <= 140 * (1 << 20):
         return list(range(N + 1))
     rows = set(range(4)) | set(range(N - 3, N + 1)) | set(range(0, N + 1, 16))
-    for chunk in ((7 * N + 15) // 16, N // 2, 32, 64):
+    for chunk in ((7 * N + 15) // 16, (N + 2) // 3, N // 2, 32, 64):
         for edge in range(chunk, N, chunk):
             rows |= set(range(max(edge - 4, 0), min(edge + 4, N) + 1))
     return sorted(rows)
