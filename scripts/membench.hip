@@ -194,6 +194,70 @@ void run_linestrips(Ptrs p, int rows, int cols4, size_t pitch4)
   }
 }
 
+// 60-lane strips (the double step's present geometry) with the stores' cache-policy bits spelt
+// out: HINT 0 plain, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1, 5 sc0 sc1 nt, 6 sc1 nt, 7 sc0 nt
+template <int HINT>
+__device__ __forceinline__ void store_hint(float4 *ptr, float4 v)
+{
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 q = {v.x, v.y, v.z, v.w};
+  if constexpr (HINT == 0) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(ptr), "v"(q) : "memory");
+  if constexpr (HINT == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(ptr), "v"(q) : "memory");
+  if constexpr (HINT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(ptr), "v"(q) : "memory");
+  if constexpr (HINT == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(ptr), "v"(q) : "memory");
+  if constexpr (HINT == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(ptr), "v"(q) : "memory");
+  if constexpr (HINT == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(ptr), "v"(q) : "memory");
+  if constexpr (HINT == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(ptr), "v"(q) : "memory");
+  if constexpr (HINT == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(ptr), "v"(q) : "memory");
+}
+
+template <int R, int W, int HINT>
+__global__ void __launch_bounds__(256) hint_kernel(Ptrs p, int rows, int cols4, size_t pitch4, int chunk)
+{
+  extern __shared__ float lds[];
+  constexpr int INNER = 60, H = 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int c = wave * INNER + lane - H;
+  if (wave * INNER >= cols4) return;
+  const bool store = lane >= H && lane < 64 - H && c >= 0 && c < cols4;
+  c = c < 0 ? 0 : (c >= cols4 ? cols4 - 1 : c);
+  const int r0 = blockIdx.y * chunk;
+  const int r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  for (int r = r0; r < r1; r++) {
+    const size_t i = (size_t)r * pitch4 + c;
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < R; k++) { float4 v = p.r[k][i]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    if (store) {
+#pragma unroll
+      for (int k = 0; k < W; k++) store_hint<HINT>(&p.w[k][i], acc);
+    }
+    if (acc.x == 12345.678f) lds[threadIdx.x] = acc.y;
+  }
+}
+
+template <int R, int W, int HINT>
+void run_hint(Ptrs p, int rows, int cols4, size_t pitch4)
+{
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const double bytes = (double)(R + W) * rows * cols4 * 16.0;
+  float ms;
+  const size_t smem = (size_t)(160 * 1024 / 3) / 1024 * 1024 - 1024;
+  CK(hipFuncSetAttribute((const void *)hint_kernel<R, W, HINT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  for (int chunk : {56, 129}) {
+    const int waves = (cols4 + 59) / 60;
+    dim3 grid((waves + 3) / 4, (rows + chunk - 1) / chunk);
+    hipLaunchKernelGGL((hint_kernel<R, W, HINT>), grid, dim3(256), smem, 0, p, rows, cols4, pitch4, chunk);
+    CK(hipEventRecord(e0));
+    for (int it = 0; it < 10; it++)
+      hipLaunchKernelGGL((hint_kernel<R, W, HINT>), grid, dim3(256), smem, 0, p, rows, cols4, pitch4, chunk);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("R=%d W=%d strips of 60 lanes, store policy %d, chunk=%4d   %8.1f GB/s\n", R, W, HINT, chunk,
+           bytes / (ms / 10 * 1e-3) / 1e9);
+  }
+}
+
 template <int R, int W, int HW, int NBAR>
 void run_wgstrips(Ptrs p, int rows, int cols4, size_t pitch4)
 {
@@ -272,6 +336,14 @@ int main(int argc, char **)
   for (int k = 0; k < 8; k++) { CK(hipMalloc(&p.r[k], n4 * 16)); CK(hipMemset(p.r[k], 0, n4 * 16)); }
   for (int k = 0; k < 8; k++) { CK(hipMalloc(&p.w[k], n4 * 16)); CK(hipMemset(p.w[k], 0, n4 * 16)); }
   CK(hipDeviceSynchronize());
+  if (argc > 5) {
+    run_hint<5, 4, 0>(p, rows, cols4, pitch4); run_hint<5, 4, 1>(p, rows, cols4, pitch4);
+    run_hint<5, 4, 2>(p, rows, cols4, pitch4); run_hint<5, 4, 3>(p, rows, cols4, pitch4);
+    run_hint<5, 4, 4>(p, rows, cols4, pitch4); run_hint<5, 4, 5>(p, rows, cols4, pitch4);
+    run_hint<5, 4, 6>(p, rows, cols4, pitch4); run_hint<5, 4, 7>(p, rows, cols4, pitch4);
+    run_hint<5, 4, 0>(p, rows, cols4, pitch4); run_hint<5, 4, 1>(p, rows, cols4, pitch4);
+    return 0;
+  }
   if (argc > 4) {
     run_strips<5, 4, 62>(p, rows, cols4, pitch4);
     run_strips<5, 4, 62, -1>(p, rows, cols4, pitch4);
