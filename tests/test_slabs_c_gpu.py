@@ -23,6 +23,7 @@ BASE = ["display=4", "E_dc=1", "E_omega=0.1", "mu=5", "alpha=1", "PhiYmin=-4", "
     (8, ["omega=40", "B=0.8", "dt=0.001", "n-harmonics=24", "g-grid=5003", "t-max=0.02"]),      # 178 iterations, 157 averaged: the chain's ring of batches turns over
     (3, ["omega=90", "B=0.03", "dt=0.0007", "n-harmonics=5", "g-grid=120001", "t-max=0.01"]),    # slabs wide enough for the parallel form of the sums
     (4, ["omega=100", "B=0.5", "dt=0.001", "n-harmonics=16", "g-grid=4001", "t-max=0.03", "E_omega=0"]),   # no averaging at all
+    (2, ["omega=100", "B=0.0019", "dt=0.001", "n-harmonics=64", "g-grid=2000001", "t-max=0.003"]),   # slabs of more than one round of workgroups: whole column strips first
 ])
 def test_program_over_ranks_writes_the_single_gpu_record(ranks, extra, tmp_path, solver_bin):
     args = BASE + extra
