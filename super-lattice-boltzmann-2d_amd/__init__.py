@@ -212,6 +212,15 @@ def lib():
         L.slb_slabs_tiptoe.argtypes, L.slb_slabs_tiptoe.restype = [vp], None
         L.slb_slabs_double_step.argtypes, L.slb_slabs_double_step.restype = [vp, fp, fp], None
         L.slb_slabs_last_step.argtypes, L.slb_slabs_last_step.restype = [vp], None
+        L.slb_slabs_step.argtypes, L.slb_slabs_step.restype = [vp], None
+        L.slb_link_rank.argtypes, L.slb_link_rank.restype = [vp], i
+        L.slb_link_nranks.argtypes, L.slb_link_nranks.restype = [vp], i
+        L.slb_solver_set_stream.argtypes, L.slb_solver_set_stream.restype = [C.POINTER(SolverStruct), vp], None
+        L.slb_solver_frame_values_device.argtypes = [C.POINTER(SolverStruct), i, C.POINTER(C.c_float), i, fp]
+        L.slb_solver_frame_values_device.restype = i
+        L.slb_slabs_av_set.argtypes, L.slb_slabs_av_set.restype = [vp, C.POINTER(C.c_float * 6)], None
+        L.slb_slabs_av_data.argtypes, L.slb_slabs_av_data.restype = [vp], vp
+        L.slb_slabs_write_frame.argtypes, L.slb_slabs_write_frame.restype = [vp, C.c_char_p, f], i
         L.slb_slabs_join.argtypes, L.slb_slabs_join.restype = [vp], None
         L.slb_slabs_av_rows.argtypes, L.slb_slabs_av_rows.restype = [vp, i, C.POINTER(C.c_void_p * 2)], None
         L.slb_slabs_av_submit.argtypes, L.slb_slabs_av_submit.restype = [vp, i, C.POINTER(C.c_float), i], None

@@ -653,6 +653,13 @@ class CSlabRun:
     def double_step(self):
         self.slb.lib().slb_slabs_double_step(self.r, None, None)
 
+    def step_fused(self):
+        """One iteration (one launch per range) with the ghost columns brought up to date:
+        what an odd number of steps ends on."""
+        self.slb.lib().slb_slabs_step(self.r)
+
+    step = step_fused
+
     def last_step(self):
         self.slb.lib().slb_slabs_last_step(self.r)
 

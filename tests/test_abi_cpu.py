@@ -36,6 +36,15 @@ def test_every_bound_function_declares_its_argument_types(slb):
         fn = getattr(L, name)
         assert fn.argtypes is not None, name
     assert L.slb_version().startswith(b"slb2d")
+    # the host engine's functions (host/slb_host.h: engine object, links, slab loop) as well
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, slb.__name__, "host", "slb_host.h")).read()
+    declared = set(re.findall(r"\b(slb_(?:slabs|link|solver)_\w+)\s*\(", header))
+    assert len(declared) > 50
+    for name in sorted(declared):
+        assert getattr(L, name).argtypes is not None, name
 
 
 def test_half_step_sweep_leaves_the_last_main_column_alone(oracle):

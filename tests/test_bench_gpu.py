@@ -85,3 +85,18 @@ def test_bench_starts_its_own_ranks():
                        capture_output=True, text=True, timeout=300, cwd=ROOT,
                        env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("gpus,steps,warmup", [(1, 7, 1), (2, 5, 3), (2, 1, 0)])
+def test_bench_takes_odd_step_counts(gpus, steps, warmup):
+    """Whatever --steps and --warmup the caller picks: an odd count ends on a single step."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", str(steps),
+                        "--warmup", str(warmup), "--repeats", "2", "--g-grid-per-gpu", "65536", "--no-cpu",
+                        "--no-two-sweep"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == gpus and d["steps"] == steps and d["warmup"] == warmup and d["value"] > 0

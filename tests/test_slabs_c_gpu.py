@@ -244,10 +244,13 @@ def test_python_wrapper_of_the_c_loop_steps_like_the_engine(slb, oracle):
         assert run.ranks_seen() == 1
         assert torch.cuda.current_stream().cuda_stream == slb.lib().slb_slabs_main_stream(run.r)
         run.tiptoe()
-        for _ in range(4):
+        for _ in range(2):
+            run.double_step()
+        run.step_fused()                      # an odd count in between: the spares follow
+        for _ in range(2):
             run.double_step()
         run.last_step()
-        orc.step(9)
+        orc.step(10)
         torch.cuda.synchronize()
         s = run.s
         total = np.empty((N + 1, M + 3), np.float32)
