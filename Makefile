@@ -19,7 +19,7 @@ CFLAGS   := -std=gnu99 -O3 -fPIC -ffp-contract=off -Wall -D__HIP_PLATFORM_AMD__ 
 HOST_SRC := $(PKG)/host/slb_globals.c $(PKG)/host/slb_bessel.c $(PKG)/host/slb_cli.c \
             $(PKG)/host/slb_solver.c $(PKG)/host/slb_main.c $(PKG)/host/slb_link.c $(PKG)/host/slb_slabs.c
 HOST_OBJ := $(HOST_SRC:.c=.o)
-HDRS     := include/slb_abi.h $(PKG)/host/slb_host.h
+HDRS     := include/slb_abi.h include/slb_slabs.h $(PKG)/host/slb_host.h
 
 all: lib bin/boltzmann_solver oracle
 

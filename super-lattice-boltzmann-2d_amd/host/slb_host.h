@@ -10,6 +10,7 @@
 #include <stddef.h>
 #include <stdio.h>
 #include "../../include/slb_abi.h"
+#include "../../include/slb_slabs.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -38,7 +39,7 @@ double slb_bessel_In(int n, double x);
 void slb_derive_and_load(void);
 
 /* ---- solver object: device arrays + ping-pong indices + loop time ------- */
-typedef struct slb_solver {
+struct slb_solver {
   int   N, M;            /* global n-harmonics, g-grid                           */
   int   rank, nranks;    /* phi_y slab index / count                             */
   int   W;               /* columns this slab owns on the half-step lattice      */
@@ -62,7 +63,7 @@ typedef struct slb_solver {
    * the calling thread's launches go (slb_push_stream / slb_set_stream) */
   void *stream;
   int   has_stream;
-} slb_solver;
+};
 
 /* Allocate the slab of rank `rank` of `nranks`, build a0 for its columns
  * (ghost columns included), a[0] <- a0, everything else zero
@@ -215,49 +216,7 @@ void  slb_apply_new_parameters(const float msg[7], float t, float *T, float *t0)
 /* ---- several GPUs: one process per phi_y slab (no counterpart in the reference) --------- */
 extern int ranks;                      /* ranks= of the command line: processes (GPUs) of the run */
 
-/* Point-to-point messages between the processes of a run (host/slb_link.c): device buffers
- * of floats, sent and received in groups on a HIP stream.  RCCL (ncclSend/ncclRecv over
- * xGMI; the library is opened at run time) or, for rehearsals with several ranks on one
- * GPU, a socket per peer with the messages staged through host memory. */
-typedef struct slb_link slb_link;
-int       slb_link_unique_id(char unique_id[128]);            /* ncclGetUniqueId, for rank 0 to hand out */
-slb_link *slb_link_open_rccl(int rank, int nranks, const char unique_id[128]);   /* current device = this rank's */
-slb_link *slb_link_open_fds(int rank, int nranks, const int *fds);               /* fds[peer], -1 for self */
-int       slb_link_rank(const slb_link *l);
-int       slb_link_nranks(const slb_link *l);
-int       slb_link_ranks_seen(const slb_link *l);             /* what the transport itself reports (ncclCommCount) */
-const char *slb_link_transport(const slb_link *l);
-void      slb_link_begin(slb_link *l);
-void      slb_link_send(slb_link *l, int peer, const float *dev, size_t n, void *hip_stream);
-void      slb_link_recv(slb_link *l, int peer, float *dev, size_t n, void *hip_stream);
-void      slb_link_end(slb_link *l, void *hip_stream);
-void      slb_link_close(slb_link *l);
-
-/* The time loop of one slab with its halo traffic and its share of av() (host/slb_slabs.c).
- * link may be NULL for a single rank.  The launches go to streams of the object's own;
- * slb_slabs_main_stream() is the one the interior launches use. */
-typedef struct slb_slabs slb_slabs;
-slb_slabs  *slb_slabs_create(int rank, int nranks, slb_link *link);
-slb_slabs  *slb_slabs_create_loopback(int rank, int nranks, slb_link *link);   /* timing aid, see slb_slabs.c */
-void        slb_slabs_destroy(slb_slabs *r);
-slb_solver *slb_slabs_solver(slb_slabs *r);
-void       *slb_slabs_main_stream(slb_slabs *r);
-int         slb_slabs_ranks_seen(slb_slabs *r);
-void        slb_slabs_tiptoe(slb_slabs *r);
-void        slb_slabs_double_step(slb_slabs *r, float *rows_first, float *rows_second);
-void        slb_slabs_step(slb_slabs *r);          /* one iteration, ghost columns refreshed */
-void        slb_slabs_last_step(slb_slabs *r);     /* the last iteration of a run: nothing travels */
-void        slb_slabs_join(slb_slabs *r);
-/* av() over slabs, bit-identical to the single-GPU av(): buffers for the next step's rows,
- * the step's loop times once it has been queued, and the end of the chain (av6 on rank 0) */
-void        slb_slabs_av_rows(slb_slabs *r, int n, float *rows[2]);
-void        slb_slabs_av_submit(slb_slabs *r, int n, const float *t, int skip);
-void        slb_slabs_av_submit_current(slb_slabs *r, float t);
-void        slb_slabs_av_finish(slb_slabs *r, float av6[6]);
-void        slb_slabs_av_set(slb_slabs *r, const float av6[6]);
-float      *slb_slabs_av_data(slb_slabs *r);
-void        slb_slabs_gather_rows(slb_slabs *r, int arr, int row0, int nrows, float *dst);
-int         slb_slabs_write_frame(slb_slabs *r, const char *name, float t);   /* a display=7 / display=8 frame over slabs */
+/* links between the processes and the slab time loop: include/slb_slabs.h */
 /* the program (every display mode, read-from=) over `nranks` processes, forked here (nothing may have
  * touched a GPU yet); parse_cmd() has run */
 int         slb_slab_main(int nranks);

@@ -26,6 +26,13 @@ def test_library_exports_every_declared_symbol(slb):
         assert getattr(L, name) is not None
     for name in globs:
         C.c_int.in_dll(L, name)
+    # the multi-GPU entry points (include/slb_slabs.h) come from the same library
+    text = open(os.path.join(ROOT, "include", "slb_slabs.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    slab_funcs = set(re.findall(r"\b(slb_(?:slabs|link)_[a-z0-9_]+)\s*\(", text))
+    assert len(slab_funcs) >= 30
+    for name in slab_funcs:
+        assert getattr(L, name) is not None and getattr(L, name).argtypes is not None, name
 
 
 def test_every_bound_function_declares_its_argument_types(slb):
@@ -40,7 +47,8 @@ def test_every_bound_function_declares_its_argument_types(slb):
     import os
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    header = open(os.path.join(root, slb.__name__, "host", "slb_host.h")).read()
+    header = open(os.path.join(root, slb.__name__, "host", "slb_host.h")).read() + \
+             open(os.path.join(root, "include", "slb_slabs.h")).read()
     declared = set(re.findall(r"\b(slb_(?:slabs|link|solver)_\w+)\s*\(", header))
     assert len(declared) > 50
     for name in sorted(declared):
