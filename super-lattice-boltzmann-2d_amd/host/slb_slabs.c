@@ -714,7 +714,7 @@ static int rank_main(int rank, int nranks, const int *fds)
 
   const int timing = getenv("SLB_TIMING") != NULL;
   int progress = 0, frame_number = 1;
-  float t = 0, t0 = 0, frame_time = 0, last_tT_reminder = 0;
+  float t = 0, t0 = 0, frame_time = 0, last_phase = 0;
   char file_name[64];
   const int total = host_M + 3;
   float *a012 = rank == 0 ? (float *)malloc(sizeof(float) * 3 * (size_t)total) : NULL;
@@ -771,14 +771,14 @@ static int rank_main(int rank, int nranks, const int *fds)
       }
       if (display == 9 && t >= t_start) {
         /* a strobe image whenever t/T wraps (reference: src/boltzmann_solver.c:260-275) */
-        float tT = t / T;
-        float tT_reminder = tT - ((int)tT);
-        if (tT_reminder < last_tT_reminder) {
+        const float periods = t / T;
+        const float phase = periods - ((int)periods);      /* float arithmetic, as the single-GPU loop has it */
+        if (phase < last_phase) {
           sprintf(file_name, "strobe%08d.data", frame_number++);
           write_strobe(r, file_name, strobe, t);
           frame_time = 0;
         }
-        last_tT_reminder = tT_reminder;
+        last_phase = phase;
       }
       if (display == 7 && k1 == 2) {                                  /* a movie frame */
         sprintf(file_name, "frame%08d.data", frame_number++);
