@@ -90,6 +90,9 @@ def _rows_to_compare(N, M):
     (128, 1 << 23),          # config 4 on a single GPU
     (256, 1 << 20),
     (130, 300001),           # odd sizes: partial last chunk, ragged last strip
+    (128, 800003),           # just over one round of workgroups: few strips left over, cut into many short chunks
+    (65, 1000001),           # odd row count under the whole-strips-first schedule
+    (200, 737290),           # a handful of strips beyond one round
 ])
 def test_full_shape_fused_forms_equal_the_two_sweep_form(slb, N, M):
     """At full size the default form (two iterations per launch, rows per workgroup chosen by
