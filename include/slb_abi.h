@@ -322,9 +322,12 @@ void  slb_pop_stream(void);
  *   of workgroups up): 20 = one halo lane and plain stores, 21 / 25 = 20 with a
  *   register budget of 2 / 4 waves per SIMD, 27 / 23 = one / four halo lanes, 29 / 30
  *   = two / four halo lanes with plain stores, 24 = nontemporal loads too, 26 = every
- *   strip cut into chunks of rows, 34 = every strip cut below four rounds of workgroups.
+ *   strip cut into chunks of rows, 34 = every strip cut below four rounds of workgroups,
+ *   38 = the four-column kernel also for launches too narrow to fill the device (which
+ *   otherwise go to the general kernel with one column per lane).
  *   slb_step_multi: 32 / 33 / 34 = two columns per lane instead of four, with a
- *   register budget of 2 / 3 / 4 waves per SIMD.
+ *   register budget of 2 / 3 / 4 waves per SIMD; 35 / 36 / 37 = one column per lane, budget
+ *   of 2 / 4 / 8 waves per SIMD.
  *   slb_seq_sum: 41..47 = other workgroup shapes.
  * n_chunk = rows per workgroup in n (0: by lattice width), block = threads (0: 256). */
 void slb_set_tuning(int variant, int n_chunk, int block);

@@ -903,8 +903,9 @@ fused2_step_kernel(const Fused2Args p)
 // output of stage q-1 of this iteration (row n+1) and of two iterations ago
 // (row n-1); stages 0 and 1 take the input lattices instead.  Every stage keeps
 // its last two output rows in registers; only the last two stages store.
-// Each hand-off costs one column of validity per side of a wave, so
-// H = ceil((2S-1)/4) halo lanes per side recompute what the neighbouring wave owns.
+// Every stage costs one column of validity per side of a wave (the first for want of a
+// neighbour lane's input, the others at each hand-off), so H = ceil(2S / V) halo lanes per
+// side recompute what the neighbouring wave owns.
 // pers_a/pers_b[q]: the array whose never-written cells (row N, boundary
 // columns) stage q's output inherits -- where the reference's ping-pong would
 // have put that lattice; for stage 2S-2 that is its own output array.
@@ -915,13 +916,15 @@ struct MultiArgs {
   const float *a0, *a_c, *b_c, *a_h, *b_h;
   const float *pers_a[Q - 1], *pers_b[Q - 1];
   float *a_o, *b_o, *a_ho, *b_ho;            // outputs of stage Q-2 (main) and Q-1 (half-step)
+  float *rows1, *rows2;                      // ROWS: [3][pitch] each: a rows 0, 1 and b row 1 of stage 0's / stage Q-2's output
   float E_dc, E_omega, B, dt, dPhi, PhiYmin, nu, nu2, nu_tilde, bdt;
   float c[2 * Q];                            // cosines, two per stage
   int N, pitch, m_offset, n_chunk, jj0;
   int jf[Q], jl[Q];                          // columns each stage produces
 };
 
-// V = columns per lane (4: 16-byte accesses; 2: half the registers per lane, twice the waves)
+// V = columns per lane (4: 16-byte accesses; 2: half the registers per lane, twice the waves;
+// 1: a quarter of the instructions per pass of the row loop, for lattices too narrow to fill the device)
 template <int V>
 __device__ __forceinline__ void widen_v(const float (&own)[V], float (&e)[V + 2])
 {
@@ -931,12 +934,14 @@ __device__ __forceinline__ void widen_v(const float (&own)[V], float (&e)[V + 2]
   e[V + 1] = from_right_lane(own[0]);
 }
 
-template <int S, int V, int MINW, bool DIAG = false>
+// ROWS (as in the double step): the three rows av() reads of the first and of the last new main
+// lattice also go to small side buffers.
+template <int S, int V, int MINW, bool DIAG = false, bool ROWS = false>
 __global__ void __launch_bounds__(256, MINW)
 multi_step_kernel(const MultiArgs<S> p)
 {
-  static_assert(V == 2 || V == 4, "two or four columns per lane");
-  constexpr int Q = 2 * S, H = (Q - 1 + V - 1) / V, INNER = 64 - 2 * H;
+  static_assert(V == 1 || V == 2 || V == 4, "one, two or four columns per lane");
+  constexpr int Q = 2 * S, H = (Q + V - 1) / V, INNER = 64 - 2 * H;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int jj   = p.jj0 + (wave * INNER + lane - H) * V;       // first own column (may be < 0)
@@ -982,14 +987,17 @@ multi_step_kernel(const MultiArgs<S> p)
     if constexpr (V == 4) {
       const float4 x = *reinterpret_cast<const float4 *>(base + row + j);
       v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-    } else {
+    } else if constexpr (V == 2) {
       const float2 x = *reinterpret_cast<const float2 *>(base + row + j);
       v[0] = x.x; v[1] = x.y;
+    } else {
+      v[0] = base[row + j];
     }
   };
   auto store_all = [&](float *base, size_t row, const float (&v)[V]) {
-    if constexpr (V == 4) *reinterpret_cast<float4 *>(base + row + j) = make_float4(v[0], v[1], v[2], v[3]);
-    else                  *reinterpret_cast<float2 *>(base + row + j) = make_float2(v[0], v[1]);
+    if constexpr (V == 4)      *reinterpret_cast<float4 *>(base + row + j) = make_float4(v[0], v[1], v[2], v[3]);
+    else if constexpr (V == 2) *reinterpret_cast<float2 *>(base + row + j) = make_float2(v[0], v[1]);
+    else                       base[row + j] = v[0];
   };
   constexpr unsigned ALL = (1u << V) - 1u;
   auto diffs = [&](const float (&own)[V], float (&d)[V]) {
@@ -1051,6 +1059,20 @@ multi_step_kernel(const MultiArgs<S> p)
             }
           }
         }
+        if constexpr (ROWS) {
+          // stage 0's rows come from the chunk that starts at row 0 (no chunk stores them), the
+          // last main lattice's from the chunk that stores them
+          if ((q == 0 || q == Q - 2) && n <= 1 && interior && (q == 0 ? n0 == 0 : (n >= n0 && n < n1))) {
+            float *rows = q == 0 && Q > 2 ? p.rows1 : p.rows2;
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+              if (ok & (1u << (q * V + k))) {
+                rows[row + j + k] = nA[q][k];
+                if (n == 1) rows[2 * P + j + k] = nB[q][k];
+              }
+            }
+          }
+        }
         if (q < Q - 1) {
           if (need & (1u << q)) {
             float xa[V], xb[V];
@@ -1063,6 +1085,16 @@ multi_step_kernel(const MultiArgs<S> p)
       } else if (q < Q - 1 && n == p.N) {
         // row N is never written: the stage's "output" there is what its buffer holds
         load4(p.pers_a[q], (size_t)n * P, nA[q]); load4(p.pers_b[q], (size_t)n * P, nB[q]);
+        if constexpr (ROWS) {
+          // a single harmonic: row 1 is the row no sweep writes, and av() reads it all the same
+          if ((q == 0 || q == Q - 2) && n == 1 && n0 == 0 && interior) {
+            float *rows = q == 0 && Q > 2 ? p.rows1 : p.rows2;
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+              if (ok & (1u << (q * V + k))) { rows[P + j + k] = nA[q][k]; rows[2 * P + j + k] = nB[q][k]; }
+            }
+          }
+        }
       }
     }
     // ---- slide every history one row up ----
@@ -1734,15 +1766,17 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
   return (int)hipGetLastError();
 }
 
-template <int S, int V, int MINW, bool DIAG = false>
+template <int S, int V, int MINW, bool DIAG = false, bool ROWS = false>
 int launch_multi(const slb_multi_geom *g, const float *a0, const float *const *in, const float *const *pers_a,
-                 const float *const *pers_b, float *const *out, const float *cosines, int block, int n_chunk)
+                 const float *const *pers_b, float *const *out, const float *cosines, int block, int n_chunk,
+                 float *rows_first = nullptr, float *rows_second = nullptr)
 {
-  constexpr int Q = 2 * S, H = (Q - 1 + V - 1) / V, INNER = 64 - 2 * H;
+  constexpr int Q = 2 * S, H = (Q + V - 1) / V, INNER = 64 - 2 * H;
   MultiArgs<S> s;
   s.a0 = a0; s.a_c = in[0]; s.b_c = in[1]; s.a_h = in[2]; s.b_h = in[3];
   for (int q = 0; q < Q - 1; q++) { s.pers_a[q] = pers_a[q]; s.pers_b[q] = pers_b[q]; }
   s.a_o = out[0]; s.b_o = out[1]; s.a_ho = out[2]; s.b_ho = out[3];
+  s.rows1 = rows_first; s.rows2 = rows_second;
   s.E_dc = g_phys.E_dc; s.E_omega = g_phys.E_omega; s.B = g_phys.B; s.dt = g_phys.dt;
   s.dPhi = g_phys.dPhi; s.PhiYmin = g_phys.PhiYmin; s.nu = g_phys.nu; s.nu2 = g_phys.nu2;
   s.nu_tilde = g_phys.nu_tilde; s.bdt = g_phys.bdt;
@@ -1759,7 +1793,7 @@ int launch_multi(const slb_multi_geom *g, const float *a0, const float *const *i
   const int waves = (hi + 1 - s.jj0 + per_wave - 1) / per_wave;
   const int wpb = block / 64;
   dim3 grid((waves + wpb - 1) / wpb, (s.N + s.n_chunk - 1) / s.n_chunk);
-  hipLaunchKernelGGL((multi_step_kernel<S, V, MINW, DIAG>), grid, dim3(block), 0, launch_stream(), s);
+  hipLaunchKernelGGL((multi_step_kernel<S, V, MINW, DIAG, ROWS>), grid, dim3(block), 0, launch_stream(), s);
   return (int)hipGetLastError();
 }
 
@@ -1986,6 +2020,28 @@ int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
   // (two rounds of workgroups rather than one: at n-harmonics 64, g-grid 2^18 chunks of 11-12
   // rows take 0.176-0.178 ms per launch, 16 rows 0.183, 22 rows 0.191, 32 rows 0.204)
   int tail_chunk = auto_chunk(s.N, hi - lo + 1, 240, block, cap, 1536);
+  // A launch too narrow to fill the device is a matter of how long one wave takes per pass of
+  // its row loop, and that is set by the instructions of a pass: the general kernel with ONE
+  // column per lane has a quarter of them (and four times the waves).  Measured on MI355X:
+  // 14.2 against 23.7 us per double step at 32 x 4096, 16.4 against 23.8 at 16 x 20000; from
+  // about 500 wave-chunks of the four-column kernel on it is slower (0.119 against 0.109 ms at
+  // 128 x 65536, 0.207 against 0.172 at 64 x 2^18).  Same stages, same point update, same bits.
+  // (Tuning variant 38 keeps the four-column kernel.)
+  if (g_variant == 0 && g_n_chunk <= 0) {
+    const int waves4 = (hi - lo + 1 + 239) / 240;
+    const int chunks4 = (s.N + tail_chunk - 1) / tail_chunk;
+    if (waves4 * chunks4 <= 512) {
+      slb_multi_geom mg;
+      mg.pitch = g->pitch; mg.m_offset = g->m_offset; mg.steps = 2;
+      for (int q = 0; q < 4; q++) { mg.j_first[q] = g->j_first[q]; mg.j_last[q] = g->j_last[q]; }
+      const float *in[4] = {a_current, b_current, a_current_hs, b_current_hs};
+      const float *pa[3] = {a_next, a_next_hs, a_out}, *pb[3] = {b_next, b_next_hs, b_out};
+      float *out[4] = {a_out, b_out, a_out_hs, b_out_hs};
+      const int nc = auto_chunk(s.N, hi - lo + 1, 56, 64, 8, 2048);
+      if (rows_first) return launch_multi<2, 1, 4, false, true>(&mg, a0, in, pa, pb, out, cosines, 64, nc, rows_first, rows_second);
+      return launch_multi<2, 1, 4>(&mg, a0, in, pa, pb, out, cosines, 64, nc);
+    }
+  }
   // tuning variant 26: every strip group cut into chunks, as for a narrow lattice
   int n_chunk = g_n_chunk > 0 ? g_n_chunk : (g_variant == 26 || s.N < 64 ? tail_chunk : 0);
   if (rows_first) return launch_fused2<3, false, true>(s, block, n_chunk, tail_chunk);
@@ -2046,6 +2102,19 @@ int slb_step_multi(const slb_multi_geom *g, const float *a0, const float *const 
       case 40: return launch_multi<4, 2, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
       case 41: return launch_multi<4, 2, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
       case 42: return launch_multi<4, 2, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      default: break;
+    }
+  }
+  // tuning variants 35..37: one column per lane, register budget of 2, 4, 8 waves per SIMD
+  if (v >= 35 && v <= 37) {
+    switch (g->steps * 10 + (v - 35)) {
+      case 20: return launch_multi<2, 1, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 21: return launch_multi<2, 1, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 22: return launch_multi<2, 1, 8>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 30: return launch_multi<3, 1, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 31: return launch_multi<3, 1, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 40: return launch_multi<4, 1, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      case 41: return launch_multi<4, 1, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
       default: break;
     }
   }

@@ -313,7 +313,7 @@ def test_double_step_bit_exact(slb, oracle, N, M, B, omega, pairs, n_chunk):
     L = slb.lib()
     try:
         sol.tiptoe()
-        for variant in (0, 20, 21, 23, 24, 25, 26, 27, 29, 30, 34):
+        for variant in (0, 20, 21, 23, 24, 25, 26, 27, 29, 30, 34, 38):
             L.slb_set_tuning(variant, n_chunk, 0)
             for _ in range(pairs):
                 sol.double_step()
@@ -331,7 +331,7 @@ def test_double_step_bit_exact(slb, oracle, N, M, B, omega, pairs, n_chunk):
         orc.close()
 
 
-@pytest.mark.parametrize("S,variant", [(1, 0), (2, 0), (3, 0), (4, 0), (2, 34), (3, 32), (3, 33), (4, 32)])
+@pytest.mark.parametrize("S,variant", [(1, 0), (2, 0), (3, 0), (4, 0), (2, 34), (3, 32), (3, 33), (4, 32), (2, 35), (2, 37), (3, 36), (4, 35), (4, 36)])
 @pytest.mark.parametrize("N,M,B,omega,n_chunk", [
     (1, 5, 0.5, 3.0, 0), (2, 61, 0.05, 100.0, 0), (5, 61, 0.05, 100.0, 2), (7, 300, 0.4, 10.0, 3),
     (32, 4096, 1.0, 1.0, 0), (33, 1000, 0.5, 30.0, 5), (16, 239, 0.3, 10.0, 0), (16, 240, 0.3, 10.0, 8),
