@@ -600,8 +600,9 @@ fused_step_kernel(const FusedArgs p)
 // rows n+-1, columns m+-1 (reference: src/boltzmann_c_solver.c:370-372, 400-402),
 // so a lane walking n upward runs A at row r, B at r-1, C at r-2, D at r-3 and
 // hands rows from stage to stage in registers; columns m+-1 come from the
-// adjacent lanes.  Three stage hand-offs cost three columns of validity per side,
-// which the one halo lane (four columns) on each side of a wave still covers.
+// adjacent lanes.  Every stage costs a column of validity per side of a wave (the first
+// for want of a neighbour lane's input, the others at each hand-off): four columns, which
+// one halo lane on each side of a wave covers.
 // Only C's and D's outputs (the lattices at t+2dt and t+5dt/2) are stored; the
 // lattices in between never reach memory: 5 reads + 4 writes = 36 B per TWO
 // lattice-point updates.
@@ -634,9 +635,9 @@ struct Fused2Args {
 // ROWS: the three rows av() reads (a rows 0 and 1, b row 1) of BOTH new main lattices are
 // also written to small side buffers, so the harmonic sums of the in-between time step can
 // be formed although that lattice itself is never stored.
-// H: halo lanes per side of a wave (1 suffices for the three hand-offs; 4 puts the 56 interior
-// lanes' stores -- 896 bytes per row -- on 128-byte line boundaries, at the price of forming
-// 8 of 64 columns twice instead of 2)
+// H: halo lanes per side of a wave (1 suffices; 2, what the launcher picks, puts the 60 interior
+// lanes' stores -- 960 bytes per row -- on 64-byte boundaries; 4 puts 896 bytes on 128-byte line
+// boundaries at the price of forming 8 of 64 columns twice)
 // NTS: non-temporal stores.  The interior lanes of a wave store pieces (992 bytes at H = 1)
 // that do not line up with 128-byte lines, so every boundary between two waves leaves a line
 // in two pieces; marked non-temporal the pieces are written out 2-10 % faster (measured on
