@@ -32,7 +32,7 @@ $(PKG)/host/%.o: $(PKG)/host/%.c $(HDRS)
 	$(CC) $(CFLAGS) -c $< -o $@
 
 $(LIB): $(PKG)/csrc/slb_kernels.o $(HOST_OBJ)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lm -ldl -Wl,-rpath,$(ROCM)/lib
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lm -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
 
 bin/boltzmann_solver: $(PKG)/host/boltzmann_solver.c $(LIB)
 	@mkdir -p bin

@@ -17,9 +17,11 @@
 #include <dlfcn.h>
 #include <errno.h>
 #include <hip/hip_runtime_api.h>
+#include <poll.h>
 #include <rccl/rccl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/socket.h>
 #include <unistd.h>
 
 #include "slb_host.h"
@@ -79,6 +81,8 @@ struct slb_link {
   int *fds;                                 /* fds transport: one socket per peer, -1 for self */
   struct { int send, peer; float *dev; size_t n; float *host; } op[LINK_MAX_OPS];
   int n_ops, in_group;
+  float *stage;                             /* fds transport: host staging of a group's messages */
+  size_t stage_floats;
 };
 
 int slb_link_unique_id(char unique_id[128])
@@ -109,6 +113,7 @@ slb_link *slb_link_open_fds(int rank, int nranks, const int *fds)
   if (!l) return NULL;
   l->rank = rank; l->nranks = nranks; l->is_rccl = 0;
   l->fds = (int *)malloc(sizeof(int) * (size_t)nranks);
+  if (!l->fds) { free(l); return NULL; }
   for (int i = 0; i < nranks; i++) l->fds[i] = fds[i];
   return l;
 }
@@ -160,14 +165,51 @@ void slb_link_recv(slb_link *l, int peer, float *dev, size_t n, void *st)
   link_op(l, 0, peer, dev, n, (hipStream_t)st);
 }
 
-static void fd_all(int fd, void *buf, size_t bytes, int writing)
+static void peer_gone(int err)
 {
-  char *p = (char *)buf;
-  while (bytes > 0) {
-    const ssize_t k = writing ? write(fd, p, bytes) : read(fd, p, bytes);
-    if (k < 0 && errno == EINTR) continue;
-    if (k <= 0) { fprintf(stderr, "ERROR: slb_link: a peer went away (%s)\n", k < 0 ? strerror(errno) : "end of stream"); exit(EXIT_FAILURE); }
-    p += k; bytes -= (size_t)k;
+  fprintf(stderr, "ERROR: slb_link: a peer went away (%s)\n", err ? strerror(err) : "end of stream");
+  exit(EXIT_FAILURE);
+}
+
+/* All messages of a group over the sockets.  Sends and receives make progress side by side
+ * (poll + non-blocking transfers), so two neighbours whose messages exceed the socket buffers
+ * cannot block each other; of the messages of one pair in one direction only the oldest
+ * unfinished one moves, because messages are matched by order. */
+static void fds_transfer(slb_link *l)
+{
+  size_t done[LINK_MAX_OPS];
+  int left = 0;
+  for (int i = 0; i < l->n_ops; i++) { done[i] = 0; left++; }
+  while (left > 0) {
+    struct pollfd pf[LINK_MAX_OPS];
+    int op_of[LINK_MAX_OPS], np = 0;
+    for (int i = 0; i < l->n_ops; i++) {
+      if (done[i] == sizeof(float) * l->op[i].n) continue;
+      int earlier = 0;
+      for (int k = 0; k < i && !earlier; k++)
+        earlier = done[k] < sizeof(float) * l->op[k].n && l->op[k].peer == l->op[i].peer && l->op[k].send == l->op[i].send;
+      if (earlier) continue;
+      pf[np].fd = l->fds[l->op[i].peer];
+      pf[np].events = l->op[i].send ? POLLOUT : POLLIN;
+      pf[np].revents = 0;
+      op_of[np++] = i;
+    }
+    if (poll(pf, (nfds_t)np, -1) < 0) {
+      if (errno == EINTR) continue;
+      peer_gone(errno);
+    }
+    for (int k = 0; k < np; k++) {
+      if (!pf[k].revents) continue;
+      const int i = op_of[k];
+      char *p = (char *)l->op[i].host + done[i];
+      const size_t rest = sizeof(float) * l->op[i].n - done[i];
+      const ssize_t got = l->op[i].send ? send(pf[k].fd, p, rest, MSG_DONTWAIT | MSG_NOSIGNAL)
+                                        : recv(pf[k].fd, p, rest, MSG_DONTWAIT);
+      if (got < 0 && (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR)) continue;
+      if (got <= 0) peer_gone(got < 0 ? errno : 0);
+      done[i] += (size_t)got;
+      if (done[i] == sizeof(float) * l->op[i].n) left--;
+    }
   }
 }
 
@@ -177,23 +219,28 @@ void slb_link_end(slb_link *l, void *stream)
   l->in_group = 0;
   if (l->is_rccl) { RCCL_OK(rccl.GroupEnd()); return; }
   /* host-staged: what the stream has produced so far goes out, what comes in is on the
-   * device before this returns.  Every message fits a socket buffer, so all ranks may
-   * write first and read afterwards. */
+   * device before this returns */
+  size_t total = 0;
+  for (int i = 0; i < l->n_ops; i++) total += l->op[i].n;
+  if (total > l->stage_floats) {
+    free(l->stage);
+    l->stage = (float *)malloc(sizeof(float) * total);
+    if (!l->stage) { fprintf(stderr, "ERROR: slb_link: out of host memory for %zu floats\n", total); exit(EXIT_FAILURE); }
+    l->stage_floats = total;
+  }
+  total = 0;
   for (int i = 0; i < l->n_ops; i++) {
-    l->op[i].host = (float *)malloc(sizeof(float) * l->op[i].n);
+    l->op[i].host = l->stage + total;
+    total += l->op[i].n;
     if (l->op[i].send)
       HIP_OK(hipMemcpyAsync(l->op[i].host, l->op[i].dev, sizeof(float) * l->op[i].n, hipMemcpyDeviceToHost, st));
   }
   HIP_OK(hipStreamSynchronize(st));
+  fds_transfer(l);
   for (int i = 0; i < l->n_ops; i++)
-    if (l->op[i].send) fd_all(l->fds[l->op[i].peer], l->op[i].host, sizeof(float) * l->op[i].n, 1);
-  for (int i = 0; i < l->n_ops; i++)
-    if (!l->op[i].send) {
-      fd_all(l->fds[l->op[i].peer], l->op[i].host, sizeof(float) * l->op[i].n, 0);
+    if (!l->op[i].send)
       HIP_OK(hipMemcpyAsync(l->op[i].dev, l->op[i].host, sizeof(float) * l->op[i].n, hipMemcpyHostToDevice, st));
-    }
   HIP_OK(hipStreamSynchronize(st));
-  for (int i = 0; i < l->n_ops; i++) free(l->op[i].host);
   l->n_ops = 0;
 }
 
@@ -205,5 +252,6 @@ void slb_link_close(slb_link *l)
     for (int i = 0; i < l->nranks; i++) if (l->fds[i] >= 0) close(l->fds[i]);
     free(l->fds);
   }
+  free(l->stage);
   free(l);
 }

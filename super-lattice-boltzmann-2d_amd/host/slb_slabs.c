@@ -26,7 +26,10 @@
  * step order.
  */
 #include <hip/hip_runtime_api.h>
+#include <errno.h>
 #include <math.h>
+#include <pthread.h>
+#include <signal.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/socket.h>
@@ -70,7 +73,16 @@ struct slb_slabs {
   long  batch_next_sum;             /* first batch whose sums have not been launched               */
   long  batch_next_send;            /* first batch whose totals have not left                      */
   float *av_data;                   /* device, 6 floats (meaningful on the last rank)              */
+  /* stall watchdog (SLB_WATCHDOG=<seconds>): what the loop was doing when it last moved */
+  volatile long ticks;              /* grows with every call into the driver and every exchange    */
+  const char *volatile where;       /* the call or wait the host thread entered last               */
+  volatile long double_steps, single_steps;
+  pthread_t dog;
+  int   dog_seconds;
+  volatile int dog_stop;
 };
+
+#define MARK(r, text) do { (r)->where = (text); (r)->ticks++; } while (0)
 
 static void check(int rc, const char *what)
 {
@@ -95,6 +107,62 @@ slb_slabs *slb_slabs_create(int rank, int nranks, slb_link *link)
 slb_slabs *slb_slabs_create_loopback(int rank, int nranks, slb_link *link)
 {
   return slabs_create(rank, nranks, link, 1);
+}
+
+/* ---- stall watchdog -----------------------------------------------------------------------
+ * SLB_WATCHDOG=<seconds>: a thread that looks at the driver's tick count once a second; when
+ * it has not moved for that long the rank writes down what it was doing -- the call the host
+ * thread is in, the exchange and batch counters of the av schedule, which streams still have
+ * work and which of the events that order them have fired -- to stderr (and to
+ * $SLB_WATCHDOG_DIR/slab_stall_rank<q>.txt) and ends the process with status 86, so that a
+ * stalled run leaves its state behind instead of being killed from outside without a trace. */
+static const char *busy_or_idle(hipError_t e)
+{
+  return e == hipSuccess ? "done" : (e == hipErrorNotReady ? "PENDING" : hipGetErrorString(e));
+}
+
+static void dump_state(slb_slabs *r, FILE *f, long idle_s)
+{
+  fprintf(f, "slab stall: rank %d of %d made no progress for %ld s\n", r->rank, r->nranks, idle_s);
+  fprintf(f, "  host thread last entered: %s (tick %ld)\n", r->where ? r->where : "(nothing yet)", r->ticks);
+  fprintf(f, "  double steps %ld, single steps %ld, exchanges %ld, side_busy %d, transport %s\n", r->double_steps,
+          r->single_steps, r->exchanges, r->side_busy, r->link ? slb_link_transport(r->link) : "none");
+  fprintf(f, "  streams: main %s, side %s, av %s\n", busy_or_idle(hipStreamQuery(r->main)),
+          busy_or_idle(hipStreamQuery(r->side)), busy_or_idle(hipStreamQuery(r->av)));
+  fprintf(f, "  events: ev_main (side waits for it) %s, ev_side (main waits for it) %s, ev_x (av waits for it) %s\n",
+          busy_or_idle(hipEventQuery(r->ev_main)), busy_or_idle(hipEventQuery(r->ev_side)),
+          busy_or_idle(hipEventQuery(r->ev_x)));
+  fprintf(f, "  av chain: batch_open %ld, next_sum %ld, next_send %ld, ring of %d\n", r->batch_open, r->batch_next_sum,
+          r->batch_next_send, r->ring_n);
+  for (int k = 0; k < r->ring_n; k++) {
+    const av_batch *b = &r->ring[k];
+    if (!b->init) continue;
+    fprintf(f, "    slot %d: lattices %d, steps %d, ready at exchange %ld, summed %d, sent %d, done-event %s\n", k, b->n,
+            b->steps, b->ready, b->summed, b->sent, busy_or_idle(hipEventQuery(b->done)));
+  }
+  fflush(f);
+}
+
+static void *watchdog(void *arg)
+{
+  slb_slabs *r = (slb_slabs *)arg;
+  long seen = r->ticks, idle = 0;
+  while (!r->dog_stop) {
+    struct timespec one = {1, 0};
+    nanosleep(&one, NULL);
+    if (r->ticks != seen) { seen = r->ticks; idle = 0; continue; }
+    if (++idle < r->dog_seconds) continue;
+    dump_state(r, stderr, idle);
+    const char *dir = getenv("SLB_WATCHDOG_DIR");
+    if (dir) {
+      char name[512];
+      snprintf(name, sizeof(name), "%s/slab_stall_rank%d.txt", dir, r->rank);
+      FILE *f = fopen(name, "w");
+      if (f) { dump_state(r, f, idle); fclose(f); }
+    }
+    _exit(86);
+  }
+  return NULL;
 }
 
 static slb_slabs *slabs_create(int rank, int nranks, slb_link *link, int loopback)
@@ -138,6 +206,9 @@ static slb_slabs *slabs_create(int rank, int nranks, slb_link *link, int loopbac
   }
   HIP_OK(hipDeviceSynchronize());
   slb_solver_set_stream(r->s, r->main);
+  const char *dog = getenv("SLB_WATCHDOG");
+  r->dog_seconds = dog ? atoi(dog) : 0;
+  if (r->dog_seconds > 0 && pthread_create(&r->dog, NULL, watchdog, r) != 0) r->dog_seconds = 0;
   return r;
 }
 
@@ -154,6 +225,7 @@ static void exchange(slb_slabs *r, float *const send[2], float *const recv[2], s
 {
   const long e = r->exchanges;
   av_batch *in = NULL, *out = NULL;
+  MARK(r, "exchange: message group");
   /* a batch arrives here AVC_LAG*rank exchanges after it was complete, and leaves AVC_LAG later */
   /* (batches complete in order and `ready` grows from batch to batch, so only the oldest
    * batch not yet summed, or not yet sent, can be due) */
@@ -201,6 +273,7 @@ static void exchange(slb_slabs *r, float *const send[2], float *const recv[2], s
  * lattice's are from the initial state) */
 void slb_slabs_tiptoe(slb_slabs *r)
 {
+  MARK(r, "slb_slabs_tiptoe");
   on_stream(r->side);
   slb_solver_tiptoe(r->s);
   for (int side = 0; side < 2; side++)
@@ -219,6 +292,8 @@ void slb_slabs_double_step(slb_slabs *r, float *rows_first, float *rows_second)
 {
   slb_solver *s = r->s;
   float c[8];
+  MARK(r, "slb_slabs_double_step");
+  r->double_steps++;
   slb_step2_cosines(s->t, c);
   const int first = s->G, last_owned = s->G + s->W - 1;
   const int lo = r->left >= 0 ? first + 4 : first;
@@ -234,12 +309,14 @@ void slb_slabs_double_step(slb_slabs *r, float *rows_first, float *rows_second)
   on_stream(r->main);
   /* spare arrays, if stale (first use, or a single step since): copied on the main stream,
    * after whatever the side stream still has to put into the lattices they are copies of */
-  if (r->side_busy && (!s->spare_a || s->spare_of != s->current || s->spare_of_hs != s->current_hs))
-    HIP_OK(hipStreamWaitEvent(r->main, r->ev_side, 0));
+  const int stale = !s->spare_a || s->spare_of != s->current || s->spare_of_hs != s->current_hs;
+  if (r->side_busy && stale) HIP_OK(hipStreamWaitEvent(r->main, r->ev_side, 0));
   slb_solver_prepare_double_step(s);
   /* halo chain: reads what the last interior launch wrote, writes the spare arrays' edge
-   * and ghost columns (which that launch read) */
-  if (!r->side_busy) HIP_OK(hipEventRecord(r->ev_main, r->main));
+   * and ghost columns (which that launch read).  When the spares were just re-copied on the
+   * main stream the event has to stand behind those copies: the side stream's edge launches
+   * and halo unpack write the same arrays. */
+  if (!r->side_busy || stale) HIP_OK(hipEventRecord(r->ev_main, r->main));
   HIP_OK(hipStreamWaitEvent(r->side, r->ev_main, 0));
   on_stream(r->side);
   if (r->left >= 0)  slb_solver_double_step_range_rows(s, first, first + 3, c, rows_first, rows_second);
@@ -276,6 +353,8 @@ void slb_slabs_join(slb_slabs *r)
  * ghost columns are stale afterwards, no further step may follow. */
 void slb_slabs_last_step(slb_slabs *r)
 {
+  MARK(r, "slb_slabs_last_step");
+  r->single_steps++;
   slb_slabs_join(r);
   slb_solver_step_fused(r->s);
   HIP_OK(hipEventRecord(r->ev_main, r->main));
@@ -288,6 +367,8 @@ void slb_slabs_last_step(slb_slabs *r)
 void slb_slabs_step(slb_slabs *r)
 {
   slb_solver *s = r->s;
+  MARK(r, "slb_slabs_step");
+  r->single_steps++;
   slb_slabs_join(r);
   slb_solver_step_fused(s);
   HIP_OK(hipEventRecord(r->ev_main, r->main));
@@ -414,6 +495,7 @@ void slb_slabs_av_submit_current(slb_slabs *r, float t)
  * data on rank 0 (other ranks: their own copy is meaningless and av6 is left alone). */
 void slb_slabs_av_finish(slb_slabs *r, float av6[6])
 {
+  MARK(r, "slb_slabs_av_finish: draining the chain");
   batch_close(r);
   /* empty exchanges until the last batch has passed the last rank */
   const long last = r->batch_open - 1;
@@ -423,8 +505,10 @@ void slb_slabs_av_finish(slb_slabs *r, float av6[6])
     while (r->exchanges <= until) exchange(r, NULL, NULL, 0);
     on_stream(r->main);
   }
+  MARK(r, "slb_slabs_av_finish: waiting for the side and av streams");
   HIP_OK(hipStreamSynchronize(r->side));
   HIP_OK(hipStreamSynchronize(r->av));
+  MARK(r, "slb_slabs_av_finish: averaging data to rank 0");
   if (r->nranks > 1) {
     /* the last rank holds the result; rank 0 writes the record */
     slb_link_begin(r->link);
@@ -458,9 +542,11 @@ void slb_slabs_av_set(slb_slabs *r, const float av6[6])
 void slb_slabs_gather_rows(slb_slabs *r, int arr, int row0, int nrows, float *dst)
 {
   slb_solver *s = r->s;
+  MARK(r, "slb_slabs_gather_rows: waiting for the main and side streams");
   slb_slabs_join(r);
   HIP_OK(hipStreamSynchronize(r->main));
   HIP_OK(hipStreamSynchronize(r->side));
+  MARK(r, "slb_slabs_gather_rows: row messages");
   const float *src = arr == 0 ? s->a0 : (arr <= 4 ? s->a[arr - 1] : s->b[arr - 5]);
   const int total = s->M + 3;
   /* my columns: the owned ones, plus the global boundary columns on the outer slabs */
@@ -510,9 +596,11 @@ typedef void (*frame_block_fn)(void *ctx, int p, float phi_x, const float *vals,
 static void frame_blocks(slb_slabs *r, int with_a0, frame_block_fn line, void *ctx)
 {
   slb_solver *s = r->s;
+  MARK(r, "frame_blocks: waiting for the main and side streams");
   slb_slabs_join(r);
   HIP_OK(hipStreamSynchronize(r->main));
   HIP_OK(hipStreamSynchronize(r->side));
+  MARK(r, "frame_blocks: frame values and their messages");
   const int m1 = s->M + 1, sets = with_a0 ? 2 : 1;
   float phis[1024];
   const int nphi = slb_frame_phi_x(phis, 1024);
@@ -639,7 +727,9 @@ int slb_slabs_ranks_seen(slb_slabs *r) { return r->link ? slb_link_ranks_seen(r-
 void slb_slabs_destroy(slb_slabs *r)
 {
   if (!r) return;
+  MARK(r, "slb_slabs_destroy: hipDeviceSynchronize");
   HIP_OK(hipDeviceSynchronize());
+  if (r->dog_seconds > 0) { r->dog_stop = 1; pthread_join(r->dog, NULL); }
   for (int k = 0; k < r->ring_n; k++) {
     for (int q = 0; q < AVC_SETS; q++) if (r->ring[k].rows[q]) hipFree(r->ring[k].rows[q]);
     if (r->ring[k].init) { hipFree(r->ring[k].init); hipFree(r->ring[k].tot); }
@@ -711,6 +801,13 @@ static int rank_main(int rank, int nranks, const int *fds)
   slb_solver *s = r->s;
   slb_set_av_mode(SLB_AV_EXACT);
   slb_slabs_tiptoe(r);
+  /* fault injection for the tests of the parent's error path: this rank ends like any of the
+   * exit(EXIT_FAILURE) paths would, while its neighbours wait for its next message */
+  const char *fail = getenv("SLB_FAIL_RANK");
+  if (fail && nranks > 1 && atoi(fail) == rank) {
+    fprintf(stderr, "ERROR: rank %d ends here (SLB_FAIL_RANK)\n", rank);
+    exit(EXIT_FAILURE);
+  }
 
   const int timing = getenv("SLB_TIMING") != NULL;
   int progress = 0, frame_number = 1;
@@ -875,10 +972,26 @@ int slb_slab_main(int nranks)
   }
   for (int i = 0; i < nranks; i++)
     for (int j = i + 1; j < nranks; j++) { close(pair[i * nranks + j][0]); close(pair[i * nranks + j][1]); }
-  int worst = EXIT_SUCCESS;
-  for (int q = 0; q < nranks; q++) {
+  /* Wait for whichever rank ends next.  A rank that fails leaves its neighbours blocked in a
+   * receive for good, so on the first abnormal end the others are ended too and the run
+   * returns failure instead of hanging. */
+  int worst = EXIT_SUCCESS, alive = nranks;
+  while (alive > 0) {
     int st = 0;
-    if (waitpid(pids[q], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) worst = EXIT_FAILURE;
+    const pid_t who = waitpid(-1, &st, 0);
+    if (who < 0) { if (errno == EINTR) continue; worst = EXIT_FAILURE; break; }
+    int q = 0;
+    while (q < nranks && pids[q] != who) q++;
+    if (q == nranks) continue;                  /* not one of the ranks */
+    pids[q] = -1;
+    alive--;
+    if (WIFEXITED(st) && WEXITSTATUS(st) == 0) continue;
+    if (worst == EXIT_SUCCESS) {
+      if (WIFSIGNALED(st)) fprintf(stderr, "ERROR: rank %d was ended by signal %d; ending the other ranks\n", q, WTERMSIG(st));
+      else                 fprintf(stderr, "ERROR: rank %d ended with status %d; ending the other ranks\n", q, WEXITSTATUS(st));
+      for (int k = 0; k < nranks; k++) if (pids[k] > 0) kill(pids[k], SIGTERM);
+    }
+    worst = EXIT_FAILURE;
   }
   free(pids); free(pair);
   return worst;

@@ -43,29 +43,41 @@ void slb_derive_and_load(void)
  * g-grid 2^20: a two-sweep launch takes 0.670 ms with 4096 bytes between the starts
  * (0.675-0.684 with 1024-8192) against 0.708 ms with none; the double step is unaffected.
  * SLB_STAGGER=<bytes> (a multiple of 16) sets another distance. */
-#define SLB_MAX_ALLOCS 64
-static struct { void *user, *base; } g_allocs[SLB_MAX_ALLOCS];
+/* (user pointer, allocation) pairs of the live lattice arrays of this process; grows as needed */
+static struct slb_alloc { void *user, *base; } *g_allocs = NULL;
+static int g_allocs_cap = 0;
 static int g_alloc_seq = 0;
 
 static hipError_t lattice_alloc(float **out, size_t bytes)
 {
   const char *e = getenv("SLB_STAGGER");
-  const size_t stagger = e ? (size_t)atol(e) / 16 * 16 : 4096;
+  long want = e ? atol(e) : 4096;
+  if (want < 0) want = 0;
+  if (want > (1L << 20)) want = 1L << 20;             /* 16 arrays: at most 15 MiB of padding each */
+  const size_t stagger = (size_t)want / 16 * 16;
   const size_t off = stagger * (size_t)(g_alloc_seq++ % 16);
+  int slot = -1;
+  for (int i = 0; i < g_allocs_cap && slot < 0; i++) if (!g_allocs[i].user) slot = i;
+  if (slot < 0) {
+    const int cap = g_allocs_cap ? 2 * g_allocs_cap : 64;
+    struct slb_alloc *t = (struct slb_alloc *)realloc(g_allocs, sizeof(*t) * (size_t)cap);
+    if (!t) return hipErrorOutOfMemory;
+    memset(t + g_allocs_cap, 0, sizeof(*t) * (size_t)(cap - g_allocs_cap));
+    slot = g_allocs_cap;
+    g_allocs = t; g_allocs_cap = cap;
+  }
   void *base = NULL;
   hipError_t rc = hipMalloc(&base, bytes + off);
   if (rc != hipSuccess) return rc;
   *out = (float *)((char *)base + off);
-  for (int i = 0; i < SLB_MAX_ALLOCS; i++)
-    if (!g_allocs[i].user) { g_allocs[i].user = *out; g_allocs[i].base = base; return hipSuccess; }
-  hipFree(base);
-  return hipErrorOutOfMemory;
+  g_allocs[slot].user = *out; g_allocs[slot].base = base;
+  return hipSuccess;
 }
 
 static void lattice_free(float *p)
 {
   if (!p) return;
-  for (int i = 0; i < SLB_MAX_ALLOCS; i++)
+  for (int i = 0; i < g_allocs_cap; i++)
     if (g_allocs[i].user == p) { hipFree(g_allocs[i].base); g_allocs[i].user = g_allocs[i].base = NULL; return; }
   hipFree(p);
 }

@@ -15,6 +15,10 @@ PKG_NAME = "super-lattice-boltzmann-2d_amd"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # Slab runs started by the tests carry a stall watchdog: a rank of the C loop that makes no
+    # progress for 60 s writes down what it was waiting for (host/slb_slabs.c, dump_state) and
+    # ends with status 86 -- before any outer time limit kills it without a trace.
+    os.environ.setdefault("SLB_WATCHDOG", "60")
 
 
 @pytest.fixture(scope="session")

@@ -72,6 +72,109 @@ def test_full_shape_windows_bit_exact(slb, oracle, N, M, steps):
         sol.close()
 
 
+def _stage_ranges(c0, c1, M, stages):
+    """Columns each of `stages` consecutive sweeps can form from a window [c0, c1] of the
+    lattices before the first of them: a sweep needs its stencil one column to each side, so
+    the range shrinks by a column per sweep at an edge of the window that is not the edge of
+    the lattice; at the lattice's own edges the sweeps' ranges are 1..M+1 (main) and 1..M."""
+    out, lo, hi = [], c0, c1
+    for q in range(stages):
+        top = M + 1 if q % 2 == 0 else M
+        lo = 1 if c0 == 0 else lo + 1
+        hi = top if c1 == M + 2 else min(hi - 1, top)
+        out.append((lo, hi))
+    return out
+
+
+def _check_double_step_on_window(sol, slb, oracle, p, c0, c1, rows=None):
+    """The default form -- two iterations per launch -- held to the oracle directly: columns
+    [c0, c1] of all nine arrays before the launch, the launch on the GPU, then its four sweeps
+    replayed on the window with the oracle (reference: src/boltzmann_c_solver.c:164-194,
+    355-411).  Each in-between lattice starts from the buffer the reference's ping-pong would
+    have put it in, the final two from the current lattices (the spare arrays are copies of
+    them), so every cell no sweep writes is what the reference finds there."""
+    s = sol.s
+    M, ncols = p.M, c1 - c0 + 1
+    before = [sol.window(k, c0, ncols) for k in ALL]
+    cur, nxt, chs, nhs = s.current, s.next, s.current_hs, s.next_hs
+    cos = slb.step2_cosines(s.t)
+    if rows is None:
+        sol.double_step()
+    else:
+        sol.double_step_rows(rows[0].data_ptr(), rows[1].data_ptr())
+    assert (s.current, s.current_hs) == (cur, chs)
+    a0 = before[0]
+    A = lambda i: before[1 + i]
+    B = lambda i: before[5 + i]
+    rng = _stage_ranges(c0, c1, M, 4)
+    o1a, o1b = A(nxt).copy(), B(nxt).copy()
+    o2a, o2b = A(nhs).copy(), B(nhs).copy()
+    o3a, o3b = A(cur).copy(), B(cur).copy()
+    o4a, o4b = A(chs).copy(), B(chs).copy()
+    sw = lambda q, ac, bc, a_s, b_s, ao, bo: oracle.sweep(p, ncols, c0, rng[q][0] - c0, rng[q][1] - c0, a0, ac, bc,
+                                                         a_s, b_s, ao, bo, cos[2 * q], cos[2 * q + 1])
+    sw(0, A(cur), B(cur), A(chs), B(chs), o1a, o1b)
+    sw(1, A(chs), B(chs), o1a, o1b, o2a, o2b)
+    sw(2, o1a, o1b, o2a, o2b, o3a, o3b)
+    sw(3, o2a, o2b, o3a, o3b, o4a, o4b)
+    for idx, (lo, hi), ea, eb in ((cur, rng[2], o3a, o3b), (chs, rng[3], o4a, o4b)):
+        for base, exp, name in ((1, ea, "a"), (5, eb, "b")):
+            got = sol.window(base + idx, lo, hi - lo + 1)
+            assert np.array_equal(got.view(np.uint32), exp[:, lo - c0:hi - c0 + 1].view(np.uint32)), (name, idx, lo, hi)
+    if rows is not None:
+        import torch
+        torch.cuda.synchronize()
+        # the three rows av() reads of the lattice after the first iteration (never stored
+        # itself) and after the second
+        for buf, (lo, hi), ea, eb in ((rows[0], rng[0], o1a, o1b), (rows[1], rng[2], o3a, o3b)):
+            hi = min(hi, M)                          # av() sums columns 1..M
+            got = buf[:, lo:hi + 1].cpu().numpy()
+            exp = np.stack([ea[0, lo - c0:hi - c0 + 1], ea[1, lo - c0:hi - c0 + 1], eb[1, lo - c0:hi - c0 + 1]])
+            assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), ("rows", lo, hi)
+
+
+@pytest.mark.parametrize("with_rows", [False, True])
+@pytest.mark.parametrize("N,M", [
+    (128, 1 << 20),          # config 3: 1.4 rounds of workgroups, whole strips first, the rest in chunks
+    (512, 1 << 20),          # config 5
+    (128, 1 << 23),          # config 4 on a single GPU: eleven rounds
+    (128, 800003),           # just over one round of workgroups
+    (64, 1 << 18),           # config 2's shape: every strip cut into short chunks
+])
+def test_full_shape_double_step_windows_bit_exact(slb, oracle, N, M, with_rows):
+    """The program's and the benchmark's default kernel under the launch schedule those shapes
+    get (whole column strips first from one round of workgroups up), with and without the row
+    buffers of the averaging period, against the oracle's four sweeps -- no other HIP kernel
+    in between.  Windows: both ends of the lattice, the centre, and the columns where the
+    strips taken whole end and the strips cut into chunks begin (768 workgroups of 960 columns
+    on a device that holds three workgroups on each of 256 compute units)."""
+    import torch
+    p = oracle.make_params(N=N, M=M, B=4000.0 / M, omega=100.0)
+    slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    sol = slb.Solver()
+    try:
+        sol.tiptoe()
+        sol.step()
+        rows = None
+        if with_rows:
+            rows = (torch.zeros((3, sol.s.pitch), dtype=torch.float32, device="cuda"),
+                    torch.zeros((3, sol.s.pitch), dtype=torch.float32, device="cuda"))
+        windows = [(0, 600), (M - 500, M + 2), (M // 2 - 300, M // 2 + 300)]
+        seam = 768 * 960
+        for k in range(1, 12):
+            if k * seam + 400 < M:
+                windows.append((k * seam - 400, k * seam + 400))
+        windows = windows[:6]
+        for c0, c1 in windows:
+            _check_double_step_on_window(sol, slb, oracle, p, c0, c1, rows)
+        row0 = sol.rows(1 + sol.s.current, 0, 1)[0]
+        norm = 2 * np.pi * np.sqrt(p.alpha) * np.sum(row0[1:M + 1].astype(np.float64) * p.dPhi)
+        assert abs(norm - 1) < 2e-4
+    finally:
+        sol.close()
+
+
 def _rows_to_compare(N, M):
     """All rows of a lattice that fits comfortably, otherwise the rows around every place a
     workgroup's chunk of rows may begin or end, the first and last rows, and every 16th."""

@@ -196,6 +196,64 @@ def test_single_rank_loop_in_c_matches_the_oracle(slb, oracle):
         orc.close()
 
 
+@pytest.mark.parametrize("ranks,plan", [
+    (2, "dsdsddsl"),        # a double step right after a single step: the spares are re-copied while the side stream is busy
+    (3, "sdsdddssdl"),
+])
+def test_c_loop_over_ranks_in_any_order_of_steps(ranks, plan, tmp_path, oracle):
+    """slb_slabs_double_step() after slb_slabs_step() on several ranks (sockets, one GPU): the
+    spare arrays are copied again on the main stream while the side stream still has halo work,
+    and the side stream's next edge launches must wait for those copies.  Every cell of both
+    current lattices, gathered over the ranks, equals the single-domain oracle's."""
+    import socket
+    import sys
+    N, M, B, omega = 12, 6007, 0.7, 30.0
+    pairs = {}
+    for i in range(ranks):
+        for j in range(i + 1, ranks):
+            pairs[(i, j)] = socket.socketpair()
+    procs = []
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "slab_c_worker.py")
+    for q in range(ranks):
+        fds = [-1] * ranks
+        for (i, j), (si, sj) in pairs.items():
+            if i == q:
+                fds[j] = si.fileno()
+            elif j == q:
+                fds[i] = sj.fileno()
+        cmd = [sys.executable, worker, str(q), str(ranks), str(tmp_path), plan, str(N), str(M), str(B), str(omega)]
+        procs.append(subprocess.Popen(cmd + [str(f) for f in fds], pass_fds=[f for f in fds if f >= 0],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for si, sj in pairs.values():
+        si.close(), sj.close()
+    outs = [p_.communicate(timeout=200)[0] for p_ in procs]
+    assert all(p_.returncode == 0 for p_ in procs), "\n".join(outs)
+    steps = sum(2 if c == "d" else 1 for c in plan)
+    p = oracle.make_params(N=N, M=M, B=B, omega=omega)
+    orc = oracle.OracleState(p)
+    try:
+        orc.step(steps)
+        got = np.load(tmp_path / "gathered.npz")
+        assert np.float32(got["t"]) == np.float32(orc.st.t)
+        assert list(got["idx"]) == [orc.st.current, orc.st.current_hs]
+        for name, which, idx in (("a_main", "a", orc.st.current), ("b_main", "b", orc.st.current),
+                                 ("a_half", "a", orc.st.current_hs), ("b_half", "b", orc.st.current_hs)):
+            assert np.array_equal(got[name].view(np.uint32), orc.array(which, idx).view(np.uint32)), name
+    finally:
+        orc.close()
+
+
+def test_a_failing_rank_ends_the_run(tmp_path, solver_bin):
+    """A rank that ends abnormally takes the run down with a non-zero status instead of leaving
+    its neighbours waiting for its messages for good (SLB_FAIL_RANK makes rank 1 end after the
+    first half step, the way any of the driver's error paths would)."""
+    args = BASE + ["omega=100", "B=0.5", "dt=0.001", "n-harmonics=8", "g-grid=2001", "t-max=0.01", "ranks=3", "o=out.txt"]
+    r = subprocess.run([solver_bin] + args, cwd=tmp_path, capture_output=True, text=True, timeout=120,
+                       env={**os.environ, "SLB_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert "rank 1 ended with status" in r.stderr, r.stderr
+
+
 def test_rccl_link_moves_a_message_on_this_gpu(slb):
     """The RCCL transport itself, as far as one GPU goes: librccl is found and opened at run
     time, a communicator of one rank comes up from an identifier made here, and a grouped

@@ -146,6 +146,27 @@ def test_program_display77_config2_full_size_identical(solver_bin, oracle, tmp_p
     assert pick(g.stdout) == pick(o.stdout) and len(pick(o.stdout)) == 11
 
 
+def test_program_display4_config3_shape_averaged_throughout(solver_bin, oracle, tmp_path):
+    """BASELINE config 3's shape as a program (display=4, n-harmonics=128, g-grid=1048576,
+    omega=100, t-max=0.001: 64 iterations, all but the first averaged): the double-step kernel
+    with the row buffers under the whole-strips-first schedule feeds the parallel exact sums,
+    and the record -- instantaneous sums, norm, period averages, absorption -- equals the CPU
+    oracle's to the last digit (reference: src/boltzmann_c_solver.c:164-194, 236-268, 413-437).
+    The oracle runs the same lattice on the host's cores (about 25 s on 16 threads)."""
+    args = ["display=4", "omega=100", "B=0.0038", "n-harmonics=128", "g-grid=1048576", "t-max=0.001"] + COMMON
+    gdir, odir = tmp_path / "gpu", tmp_path / "orc"
+    gdir.mkdir(), odir.mkdir()
+    g = subprocess.run([solver_bin] + args + ["o=out.txt"], cwd=gdir, capture_output=True, text=True, timeout=600,
+                       env={**os.environ, "SLB_TIMING": "1"})
+    assert g.returncode == 0, g.stdout + g.stderr
+    assert "64 iterations" in g.stderr, g.stderr
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or 16
+    oracle.run_cli(args + ["o=out.txt"], cwd=odir, threads=threads, timeout=900)
+    got, exp = (gdir / "out.txt").read_text(), (odir / "out.txt").read_text()
+    assert len(exp.splitlines()) == 3
+    assert got == exp
+
+
 def test_program_display8_identical(solver_bin, oracle, tmp_path):
     args = ["display=8", "omega=100", "B=0.5", "n-harmonics=8", "g-grid=61", "t-max=0.01"] + COMMON
     gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
