@@ -21,7 +21,7 @@ HOST_SRC := $(PKG)/host/slb_globals.c $(PKG)/host/slb_bessel.c $(PKG)/host/slb_c
 HOST_OBJ := $(HOST_SRC:.c=.o)
 HDRS     := include/slb_abi.h include/slb_slabs.h $(PKG)/host/slb_host.h
 
-all: lib bin/boltzmann_solver oracle
+all: lib bin/boltzmann_solver bin/dropin_host bin/dropin_host_rdynamic oracle
 
 lib: $(LIB)
 
@@ -38,11 +38,22 @@ bin/boltzmann_solver: $(PKG)/host/boltzmann_solver.c $(LIB)
 	@mkdir -p bin
 	$(CC) $(CFLAGS) -o $@ $< -L$(PKG) -lslb2d -Wl,-rpath,'$$ORIGIN/../$(PKG)' -Wl,-rpath,$(ROCM)/lib -lm
 
+# A host in the reference's shape (it defines the host_* parameters itself and owns the device
+# memory), linked against the library the way the reference links its kernels' object:
+# once as is, once with -rdynamic.  Used by tests/test_dropin_gpu.py.
+DROPIN_LINK = -L$(PKG) -lslb2d -L$(ROCM)/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../$(PKG)' -Wl,-rpath,$(ROCM)/lib -lm
+bin/dropin_host: tests/dropin/dropin_host.c $(LIB)
+	@mkdir -p bin
+	$(CC) -std=gnu99 -O3 -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include -o $@ $< $(DROPIN_LINK)
+bin/dropin_host_rdynamic: tests/dropin/dropin_host.c $(LIB)
+	@mkdir -p bin
+	$(CC) -std=gnu99 -O3 -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include -rdynamic -o $@ $< $(DROPIN_LINK)
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(PKG)/csrc/*.o $(PKG)/host/*.o $(LIB) bin/boltzmann_solver
+	rm -f $(PKG)/csrc/*.o $(PKG)/host/*.o $(LIB) bin/boltzmann_solver bin/dropin_host bin/dropin_host_rdynamic
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib oracle clean

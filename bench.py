@@ -8,6 +8,13 @@ the roofline shape, n-harmonics=128 and g-grid=2^20 PER GPU: at
 (g-grid=2^23), so the scaling reported is weak scaling.
 
     python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --scaling strong --g-grid 8388608     # config 4 itself, cut into N slabs
+
+With N > 1 the phi_y slabs are driven by the C slab loop, which calls RCCL itself (one
+communicator; torch.distributed, over gloo, only hands round the identifier, holds the
+barriers and takes the maximum of the wall times).  Before anything is timed every rank
+checks that the ghost columns its neighbours sent it are bit for bit the columns those
+neighbours own, and the run ends non-zero, naming rank and peer, if they are not.
 
 With N > 1 and no WORLD_SIZE in the environment this process only starts the N
 ranks (python -m torch.distributed.run ... bench.py, one per GPU) before it has
@@ -126,6 +133,11 @@ def parse_args(argv=None):
                     help="timed blocks of --steps steps each; the median block is reported")
     ap.add_argument("--n-harmonics", type=int, default=N_HARMONICS)
     ap.add_argument("--g-grid-per-gpu", type=int, default=G_GRID_PER_GPU)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): --g-grid-per-gpu columns on every GPU; strong: --g-grid columns "
+                         "in all, cut into one slab per GPU")
+    ap.add_argument("--g-grid", type=int, default=1 << 23,
+                    help="--scaling strong: columns of the whole lattice (default 2^23 = config 4)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--n-chunk", type=int, default=0)
     ap.add_argument("--block", type=int, default=0)
@@ -136,7 +148,11 @@ def parse_args(argv=None):
     ap.add_argument("--driver", choices=("auto", "c", "torch"), default="auto",
                     help="N > 1: who orders the slab launches and moves the halo columns. c: the C slab "
                          "driver calling RCCL itself (host/slb_slabs.c); torch: torch.distributed "
-                         "point-to-point operations (dist.py); auto: c over RCCL, torch for gloo rehearsals")
+                         "point-to-point operations (dist.py); auto: c for the double step (the run fails "
+                         "if that driver cannot start -- it never changes silently), torch for the other "
+                         "forms.  SLB_DIST_BACKEND=gloo (rehearsals with several ranks on one GPU): the C "
+                         "driver's messages go over sockets instead of RCCL")
+    ap.add_argument("--no-self-check", action="store_true", help="N > 1: skip the ghost-column check before timing")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-two-sweep", action="store_true", help="skip the two-sweep leg of the default run")
     ap.add_argument("--two-sweep-steps", type=int, default=10)
@@ -225,6 +241,65 @@ def run_single(args, slb, torch, form, steps, warmup, repeats):
     return blocks
 
 
+def ghost_self_check(slb, run, driver, rank, world, dist):
+    """After the warm-up steps, before anything is timed: the ghost columns of both current
+    lattices on every rank must be, bit for bit, the outermost columns its neighbours own --
+    they were sent through the driver's own exchange (slb_slabs_double_step: pack, RCCL
+    send/recv, unpack; 3 columns of the main lattice, 4 of the half-step lattice).  Every rank
+    learns the verdict; a mismatch ends the run non-zero naming rank, peer and lattice."""
+    import numpy as np
+    import torch
+    run.join() if hasattr(run, "join") else None
+    torch.cuda.synchronize()
+    sol = run.s if driver == "c" else run.eng.sol.s
+    solp = slb.lib().slb_slabs_solver(run.r) if driver == "c" else run.eng.sol._p
+    G, W, rows = sol.G, sol.W, sol.N + 1
+
+    def window(arr, col0, ncols):
+        out = np.empty((rows, ncols), dtype=np.float32)
+        rc = slb.lib().slb_solver_get_window(solp, arr, col0, ncols, out.ctypes.data)
+        if rc:
+            raise SystemExit(f"rank {rank}: slb_solver_get_window -> {rc}")
+        return out
+
+    lattices = (("main", 1 + sol.current, 5 + sol.current, 3), ("half-step", 1 + sol.current_hs, 5 + sol.current_hs, 4))
+    mine = {}
+    for name, ia, ib, depth in lattices:
+        for arr_name, arr in (("a", ia), ("b", ib)):
+            mine[(name, arr_name, "own_left")] = window(arr, G, depth)                 # what rank-1 should hold as its right ghosts
+            mine[(name, arr_name, "own_right")] = window(arr, G + W - depth, depth)    # what rank+1 should hold as its left ghosts
+            mine[(name, arr_name, "ghost_left")] = window(arr, G - depth, depth)
+            mine[(name, arr_name, "ghost_right")] = window(arr, G + W, depth)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    bad = []
+    for name, _, _, depth in lattices:
+        for arr_name in ("a", "b"):
+            if rank > 0:
+                exp = everyone[rank - 1][(name, arr_name, "own_right")]
+                if not np.array_equal(mine[(name, arr_name, "ghost_left")].view(np.uint32), exp.view(np.uint32)):
+                    bad.append(f"rank {rank}: left ghost columns of {arr_name} ({name} lattice) differ from what peer {rank - 1} owns")
+            if rank < world - 1:
+                exp = everyone[rank + 1][(name, arr_name, "own_left")]
+                if not np.array_equal(mine[(name, arr_name, "ghost_right")].view(np.uint32), exp.view(np.uint32)):
+                    bad.append(f"rank {rank}: right ghost columns of {arr_name} ({name} lattice) differ from what peer {rank + 1} owns")
+    # a lattice that never moved would pass trivially: the edge columns must have changed since t = 0
+    moved = bool(np.any(mine[("half-step", "b", "own_left")] != 0))
+    if not moved:
+        bad.append(f"rank {rank}: the half-step lattice's b is still zero after the warm-up steps")
+    verdicts = [None] * world
+    dist.all_gather_object(verdicts, bad)
+    problems = [m for v in verdicts for m in v]
+    if problems:
+        if rank == 0:
+            sys.stderr.write("bench: halo self-check FAILED\n" + "\n".join(problems) + "\n")
+        dist.barrier()
+        raise SystemExit(3)
+    return {"ok": True, "ranks": world,
+            "checked": "ghost columns of both current lattices (3 main, 4 half-step per side, a and b, all rows) "
+                       "equal the neighbours' owned edge columns bit for bit after the warm-up steps"}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -244,16 +319,27 @@ def main():
     # ranks on one GPU); halo messages are then staged through host memory
     backend = os.environ.get("SLB_DIST_BACKEND", "nccl")
     ranks_seen = 1
+    driver = None
     if world > 1:
+        driver = args.driver
+        if driver == "auto":
+            driver = "c" if args.form == "double" else "torch"
+        if driver == "c" and args.form != "double":
+            raise SystemExit("--driver c runs the double step only")
         import torch.distributed as dist
-        if backend == "nccl":
+        # The C driver owns the one RCCL communicator of the run (ncclCommInitRank in
+        # host/slb_link.c); torch.distributed is then control plane only and runs over gloo.
+        # The torch driver moves the halo columns with torch's own point-to-point operations
+        # and needs the process group on RCCL.
+        if driver == "torch" and backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group("gloo")
+        control_on_gpu = dist.get_backend() == "nccl"
         ranks_seen = dist.get_world_size()
 
     n_harm = args.n_harmonics
-    g_grid = args.g_grid_per_gpu * world
+    g_grid = args.g_grid if args.scaling == "strong" else args.g_grid_per_gpu * world
     phys = dict(E_dc=1.0, E_omega=0.1, omega=100.0, mu=5.0, alpha=1.0, B=4000.0 / g_grid,
                 PhiYmin=-4.0, PhiYmax=4.0, dt=0.001)
     slb.configure(N=n_harm, M=g_grid, t_start=1.0, **phys)
@@ -267,30 +353,21 @@ def main():
     L.slb_set_tuning(args.variant, args.n_chunk, args.block)
     repeats = max(args.repeats, 1)
 
-    driver = None
+    per_rank_ms = None
+    self_check = None
     if world == 1:
         blocks = run_single(args, slb, torch, args.form, args.steps, args.warmup, repeats)
     else:
-        import torch.distributed as dist
         drv = importlib.import_module("super-lattice-boltzmann-2d_amd.dist")
-        driver = args.driver
-        if driver == "auto":
-            driver = "c" if (backend == "nccl" and args.form == "double") else "torch"
-        if driver == "c" and (backend != "nccl" or args.form != "double"):
-            raise SystemExit("--driver c runs the double step over RCCL only")
-        run = None
         if driver == "c":
-            try:
-                run = drv.CSlabRun(slb, rank, world, backend)
-                ranks_seen = run.ranks_seen()
-            except RuntimeError as e:                    # raised on every rank alike
-                if args.driver == "c":
-                    raise
-                if rank == 0:
-                    sys.stderr.write(f"bench: C slab driver unavailable ({e}); using torch.distributed\n")
-                driver = "torch"
-        if run is None:
+            run = drv.CSlabRun(slb, rank, world, backend)        # raises on every rank alike
+            transport = run.transport()                          # "rccl", or "fds" in a rehearsal
+            ranks_seen = run.ranks_seen()                        # ncclCommCount of the C driver's communicator
+            if ranks_seen != world:
+                raise SystemExit(f"rank {rank}: RCCL reports {ranks_seen} ranks, expected {world}")
+        else:
             run = drv.SlabRun(slb, rank, world)
+            transport = "torch.distributed " + dist.get_backend()
         run.tiptoe()
 
         def advance(nsteps):
@@ -303,7 +380,13 @@ def main():
                 (run.step if args.form == "sweeps" else run.step_fused)()
 
         advance(max(args.warmup + args.warmup % 2, 2))
+        if args.no_self_check or args.form != "double":
+            self_check = {"ok": None, "skipped": "--no-self-check" if args.no_self_check else
+                          "the check knows the ghost depth of the double step only"}
+        else:
+            self_check = ghost_self_check(slb, run, driver, rank, world, dist)
         blocks = []
+        mine = []
         for _ in range(repeats):
             torch.cuda.synchronize()
             dist.barrier()
@@ -314,6 +397,7 @@ def main():
             advance(args.steps)
             ev1.record()
             torch.cuda.synchronize()
+            t_mine = time.perf_counter() - t0            # this rank's own loop, before it waits for the others
             dist.barrier()
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
@@ -322,9 +406,14 @@ def main():
                 # this rank's stream time per double step: the interior launch (the edge launches
                 # and the halo traffic run beside it) plus whatever it had to wait for
                 kernel_ms = ev0.elapsed_time(ev1) / (args.steps // 2)
-            w = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            w = torch.tensor([wall], dtype=torch.float64, device="cuda" if control_on_gpu else "cpu")
             dist.all_reduce(w, op=dist.ReduceOp.MAX)
             blocks.append((float(w.item()), kernel_ms))
+            mine.append(t_mine / args.steps * 1e3)
+        mine.sort()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine[(len(mine) - 1) // 2])
+        per_rank_ms = gathered
         run.close()
 
     wall, kernel_ms = median_block(blocks)
@@ -340,10 +429,10 @@ def main():
         "ms_per_step": wall / args.steps * 1e3,
         "repeats": repeats,
         "ms_per_step_min": min(walls) / args.steps * 1e3, "ms_per_step_max": max(walls) / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (analytic equilibrium initial state, no RNG)",
         "config": {"workload": f"n-harmonics={n_harm} g-grid={g_grid} "
-                               f"({args.g_grid_per_gpu} columns per GPU, phi_y slabs) "
+                               f"({g_grid // world} columns per GPU, phi_y slabs) "
                                f"omega=100 B={phys['B']:.6g} dt=0.001, 2 sweeps per step",
                    "form": args.form, "parallelism": f"phi_y-slab x{world}"},
         # whole-job rate against the per-GPU HBM peak, with the bytes this form must move ...
@@ -355,6 +444,11 @@ def main():
         out["config"]["driver"] = {"c": "C slab driver, RCCL send/recv called from C",
                                    "torch": "torch.distributed point-to-point operations"}[driver]
         out["config"]["backend"] = backend
+        out["config"]["transport"] = transport
+        out["config"]["control_plane"] = "torch.distributed over " + dist.get_backend()
+        out["driver_ran"] = driver
+        out["ms_per_step_by_rank"] = per_rank_ms
+        out["self_check"] = self_check
     if rank == 0:
         if kernel_ms is not None:
             traffic, source = (None, None)

@@ -251,7 +251,9 @@ int slb_av_update_exact(const float *tot3, float *av_data, float t);
  *   SLB_AV_TREE -- slb_av_partial + slb_av_update: wave64 shuffle tree in
  *       double; differs from the CPU's sequential float sum by that sum's own
  *       rounding noise (about 1e-4 relative at M = 2^20 for a sum that nearly
- *       cancels, 1e-6 for one that does not). */
+ *       cancels, 1e-6 for one that does not).  At large M this mode therefore does
+ *       NOT keep the averaged drift velocity within 1e-6 relative of the CPU
+ *       solver's; only SLB_AV_EXACT and SLB_AV_CHAIN do.  Opt-in, never the default. */
 enum { SLB_AV_EXACT = 0, SLB_AV_TREE = 1, SLB_AV_CHAIN = 2 };
 void slb_set_av_mode(int mode);
 
@@ -287,14 +289,16 @@ int slb_seq_sum_stats(const float *x, int n, float *out, int *stats);
  * statically allocated device array (24 608 bytes on every GPU the library runs on, held
  * until the process ends) and calls no hipMalloc, hipFree or other allocating routine.
  * Same arguments as av() without `blocks`, same effect on av_data[0..5], bit for bit.
- * Limit: g-grid <= SLB_AV_STATIC_MAX_COLUMNS (one workspace entry per 2048 columns);
- * beyond it the call prints the reason and returns -1 without launching.  Returns 0, -1
- * for an argument error, or a hipError_t value.  All calls on one GPU share that GPU's
- * array: calls that overlap there (different streams, different threads) race; calls on
- * one stream do not.  slb_static_init() looks the array's device address up for the
+ * The workspace does not grow with the lattice (the tree sums use at most 1024 blocks of
+ * partials whose threads stride over the columns, the exact sums none), so every g-grid av()
+ * takes is taken here too; the call refuses only what av() cannot do either (load_data() not
+ * called yet, a null array) -- it prints the reason and returns -1 without launching.
+ * Returns 0, -1 for an argument error, or a hipError_t value.  All calls on one GPU share
+ * that GPU's array: calls that overlap there (different streams, different threads) race;
+ * calls on one stream do not.  slb_static_init() looks the array's device address up for the
  * current device (also done by the first slb_av_static() there); call it once per device
- * at set-up if the first slb_av_static() would otherwise fall inside a graph capture. */
-#define SLB_AV_STATIC_MAX_COLUMNS 2097152
+ * at set-up if the first slb_av_static() would otherwise fall inside a graph capture, where
+ * the whole call then records as kernel nodes only. */
 int slb_static_init(void);
 int slb_av_static(float *a, float *b, float *av_data, float t);
 
@@ -324,7 +328,8 @@ void  slb_pop_stream(void);
  *   = two / four halo lanes with plain stores, 24 = nontemporal loads too, 26 = every
  *   strip cut into chunks of rows, 34 = every strip cut below four rounds of workgroups,
  *   38 = the four-column kernel also for launches too narrow to fill the device (which
- *   otherwise go to the general kernel with one column per lane).
+ *   otherwise go to the general kernel with one column per lane), 39 = the schedule taken
+ *   when the device's occupancy cannot be queried (every strip cut into chunks of rows).
  *   slb_step_multi: 32 / 33 / 34 = two columns per lane instead of four, with a
  *   register budget of 2 / 3 / 4 waves per SIMD; 35 / 36 / 37 = one column per lane, budget
  *   of 2 / 4 / 8 waves per SIMD.

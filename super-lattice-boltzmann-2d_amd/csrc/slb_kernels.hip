@@ -46,7 +46,6 @@ double     *g_ws = nullptr;          // reduction workspace, allocated once
 int         g_ws_device = -1;
 constexpr int kMaxAvBlocks = 1024;
 constexpr int kAvColsPerBlock = 256 * 8;   // columns a block of the tree sums takes per pass
-static_assert(SLB_AV_STATIC_MAX_COLUMNS == kMaxAvBlocks * kAvColsPerBlock, "slb_abi.h states the limit");
 
 struct SweepArgs {
   const float *a0, *a_c, *b_c, *a_s, *b_s;
@@ -1731,7 +1730,8 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
   const int wpb = block / 64;
   const int groups = (waves + wpb - 1) / wpb;
   auto chunks_of = [&](int len) { return (args.N + len - 1) / len; };
-  const int slots = n_chunk > 0 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL>, block);
+  // (tuning variant 39: as if the occupancy query had failed -- every strip is cut into chunks)
+  const int slots = n_chunk > 0 || g_variant == 39 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL>, block);
   // (measured on MI355X with two halo lanes and non-temporal stores: whole groups first wins
   // from one round of workgroups up -- 2.02 against 2.11 ms at 128 rows x 2^21 columns, 2.06
   // against 2.15 at 256 x 2^20, 0.53 against 0.57 at 64 x 2^20, 1.02-1.04 against 1.03-1.08 at
@@ -2354,13 +2354,9 @@ int slb_av_static(float *a, float *b, float *av_data, float t)
 {
   if (!g_phys.loaded) { fprintf(stderr, "slb_av_static: load_data() has not been called\n"); return -1; }
   if (!a || !b || !av_data) { fprintf(stderr, "slb_av_static: null array\n"); return -1; }
-  // the static workspace holds one partial per block of the tree sums and a block takes
-  // kAvColsPerBlock columns: that many columns at most, whichever way the sums are formed
-  if (g_phys.TMSIZE - 1 > SLB_AV_STATIC_MAX_COLUMNS) {
-    fprintf(stderr, "slb_av_static: g-grid %d is beyond the %d columns the static workspace is sized for; use av()\n",
-            g_phys.TMSIZE - 1, SLB_AV_STATIC_MAX_COLUMNS);
-    return -1;
-  }
+  // No limit on g-grid: the workspace does not grow with it.  The tree sums use at most
+  // kMaxAvBlocks blocks whose threads stride over the columns, the exact sums keep no per-block
+  // partials at all; either way the kWsDoubles entries of the static array are all that is used.
   double *ws = nullptr;
   int rc = static_workspace(&ws);
   if (rc == 0) rc = av_with_workspace(ws, a, b, av_data, t);

@@ -614,17 +614,22 @@ class CSlabRun:
     """The slab time loop of host/slb_slabs.c -- launch order, halo messages and the av chain
     in C, RCCL called from C -- for a process that torch.distributed.run started: the same
     tiptoe() / double_step() / close() as SlabRun.  torch.distributed only hands rank 0's RCCL
-    identifier to the other ranks.  torch's current stream becomes the loop's main stream, so
+    identifier to the other ranks (backend "nccl"; with any other backend the messages go over
+    sockets between the ranks, for rehearsals with several ranks on one GPU).  torch's current stream becomes the loop's main stream, so
     events recorded by the caller bracket the interior launches."""
 
     def __init__(self, slb, rank, world, backend="nccl"):
         self.slb, self.rank, self.world = slb, rank, world
         L = slb.lib()
         self.link = None
-        if world > 1:
-            if backend != "nccl":
-                raise RuntimeError("CSlabRun moves its messages over RCCL; rehearsals on one GPU use "
-                                   "SlabRun (gloo) or the C program's own ranks= mode")
+        if world > 1 and backend != "nccl":
+            # rehearsal where RCCL cannot run (several ranks on one GPU): the same C loop with its
+            # messages staged over sockets between the ranks, as `boltzmann_solver ranks=N` does
+            fds = self._socket_mesh(rank, world)
+            self.link = L.slb_link_open_fds(rank, world, (C.c_int * world)(*fds))
+            if not self.link:
+                raise RuntimeError("slb_link_open_fds failed")
+        elif world > 1:
             ident = C.create_string_buffer(128)
             ok = rank != 0 or L.slb_link_unique_id(ident) == 0
             box = [ident.raw if ok else None]
@@ -639,6 +644,43 @@ class CSlabRun:
             raise RuntimeError("slb_slabs_create failed")
         self.stream = torch.cuda.ExternalStream(L.slb_slabs_main_stream(self.r))
         torch.cuda.set_stream(self.stream)
+
+    @staticmethod
+    def _socket_mesh(rank, world):
+        """A TCP connection on the loopback interface to every other rank (ports handed round
+        with torch.distributed); returns the descriptors, -1 for this rank itself.  The link
+        owns them afterwards."""
+        import socket
+        import struct
+        srv = socket.socket()
+        srv.bind(("127.0.0.1", 0))
+        srv.listen(world)
+        ports = [None] * world
+        dist.all_gather_object(ports, srv.getsockname()[1])
+        socks = [None] * world
+        for q in range(rank + 1, world):              # the lower rank connects, the higher one accepts
+            c = socket.create_connection(("127.0.0.1", ports[q]))
+            c.sendall(struct.pack("i", rank))
+            socks[q] = c
+        for _ in range(rank):
+            c, _addr = srv.accept()
+            hello = b""
+            while len(hello) < 4:
+                hello += c.recv(4 - len(hello))
+            socks[struct.unpack("i", hello)[0]] = c
+        srv.close()
+        fds = []
+        for q, c in enumerate(socks):
+            if c is None:
+                fds.append(-1)
+                continue
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            c.setblocking(True)
+            fds.append(c.detach())
+        return fds
+
+    def transport(self):
+        return self.slb.lib().slb_link_transport(self.link).decode() if self.link else "none"
 
     @property
     def s(self):

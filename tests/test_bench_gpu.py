@@ -43,16 +43,19 @@ def test_bench_prints_one_json_line(form):
         assert abs(two["frac"] - two["achieved"] / two["peak"]) < 1e-12
 
 
-def test_bench_over_two_slabs_prints_the_whole_job_rate():
-    """Two ranks sharing the GPU (halos staged over gloo, since RCCL refuses two ranks on one
-    device): rank 0 prints one line, `value` counts the columns of both slabs."""
+@pytest.mark.parametrize("driver", ["auto", "torch"])
+def test_bench_over_two_slabs_prints_the_whole_job_rate(driver):
+    """Two ranks sharing the GPU (RCCL refuses two ranks on one device, so the C slab driver's
+    messages go over sockets, the torch driver's over gloo): rank 0 prints one line, `value`
+    counts the columns of both slabs, the line says which driver ran, what each rank took,
+    and that the ghost-column check before the timing passed."""
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
-           "--warmup", "2", "--g-grid-per-gpu", "65536"]
+           "--warmup", "2", "--g-grid-per-gpu", "65536", "--driver", driver]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT,
                        env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
     assert r.returncode == 0, r.stdout + r.stderr
@@ -60,6 +63,10 @@ def test_bench_over_two_slabs_prints_the_whole_job_rate():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert d["driver_ran"] == ("c" if driver == "auto" else "torch") and d["ranks_seen"] == 2
+    assert d["config"]["transport"] == ("fds" if driver == "auto" else "torch.distributed gloo")
+    assert d["self_check"]["ok"] is True and d["self_check"]["ranks"] == 2
+    assert len(d["ms_per_step_by_rank"]) == 2 and all(0 < x <= d["ms_per_step_max"] * 1.001 for x in d["ms_per_step_by_rank"])
     assert "g-grid=131072" in d["config"]["workload"] and d["config"]["parallelism"] == "phi_y-slab x2"
     assert abs(d["ms_per_step"] * 1e-3 * d["value"] - 128 * 131072) < 1e-3 * 128 * 131072
     assert d["roofline"]["kernel"] == "fused2_step_kernel" and "note" in d["roofline"]
@@ -85,6 +92,20 @@ def test_bench_starts_its_own_ranks():
                        capture_output=True, text=True, timeout=300, cwd=ROOT,
                        env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
     assert r.returncode != 0
+
+
+def test_bench_strong_scaling_cuts_one_lattice_into_slabs():
+    """--scaling strong --g-grid G: the whole job is ONE lattice of G columns whatever the
+    number of GPUs (how config 4 is run on 2, 4 and 8 of them)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "4", "--warmup", "2",
+                        "--repeats", "2", "--scaling", "strong", "--g-grid", "300000"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 3 and d["scaling"] == "strong" and "g-grid=300000 " in d["config"]["workload"]
+    assert abs(d["ms_per_step"] * 1e-3 * d["value"] - 128 * 300000) < 1e-3 * 128 * 300000
+    assert d["self_check"]["ok"] is True and d["driver_ran"] == "c"
 
 
 @pytest.mark.parametrize("gpus,steps,warmup", [(1, 7, 1), (2, 5, 3), (2, 1, 0)])

@@ -334,7 +334,7 @@ def test_double_step_bit_exact(slb, oracle, N, M, B, omega, pairs, n_chunk):
     L = slb.lib()
     try:
         sol.tiptoe()
-        for variant in (0, 20, 21, 23, 24, 25, 26, 27, 29, 30, 34, 38):
+        for variant in (0, 20, 21, 23, 24, 25, 26, 27, 29, 30, 34, 38, 39):
             L.slb_set_tuning(variant, n_chunk, 0)
             for _ in range(pairs):
                 sol.double_step()
@@ -433,6 +433,47 @@ def test_double_step_hands_out_the_rows_av_reads(slb, oracle, N, M, B, omega):
         assert np.array_equal(av_dev.cpu().numpy().view(np.uint32), av_cpu.view(np.uint32))
         _compare_live_state(sol, orc, M)
     finally:
+        sol.close()
+        orc.close()
+
+
+@pytest.mark.parametrize("M", [30000, 31000])        # 125 and 130 waves of 240 columns, four chunks of rows each
+@pytest.mark.parametrize("variant", [0, 38, 39])
+def test_both_sides_of_the_narrow_launch_threshold(slb, oracle, M, variant):
+    """Launches of at most 512 wave-chunks go to the one-column-per-lane kernel, wider ones to
+    the four-column kernel; which one a lattice gets depends on its width (and the chunking on
+    the device's occupancy).  Just under and just over the switch, with the row buffers of the
+    averaging period: the default choice, the four-column kernel forced (38) and the
+    occupancy-unknown schedule (39) all leave the oracle's bits, lattices and rows alike."""
+    import torch
+    N = 16
+    p = oracle.make_params(N=N, M=M, B=0.3, omega=20.0)
+    slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    orc = oracle.OracleState(p)
+    sol = slb.Solver()
+    L = slb.lib()
+    try:
+        sol.tiptoe()
+        L.slb_set_tuning(variant, 0, 0)
+        rows = [torch.zeros((3, sol.s.pitch), dtype=torch.float32, device="cuda") for _ in range(2)]
+        for pair in range(3):
+            if pair == 1:
+                sol.double_step()
+                orc.step(2)
+                continue
+            sol.double_step_rows(rows[0].data_ptr(), rows[1].data_ptr())
+            torch.cuda.synchronize()
+            for k in range(2):
+                orc.step(1)
+                cur = orc.st.current
+                a, b = orc.array("a", cur), orc.array("b", cur)
+                got = rows[k].cpu().numpy()
+                for r, exp in ((0, a[0]), (1, a[1]), (2, b[1])):
+                    assert np.array_equal(got[r, 1:M + 1].view(np.uint32), exp[1:M + 1].view(np.uint32)), (pair, k, r)
+        _compare_live_state(sol, orc, M)
+    finally:
+        L.slb_set_tuning(0, 0, 0)
         sol.close()
         orc.close()
 
