@@ -172,6 +172,32 @@ int slb_step_fused2_rows(const slb_step2_geom *geom, const float *a0,
                          float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
                          const float cosines[8], float *rows_first, float *rows_second);
 
+/* The equilibrium coefficients in separable form.  a0[n][m] is the product of a factor of the
+ * row and a factor of the column (reference: src/boltzmann_c_solver.c:117-122: a float
+ * coefficient of n times a long-double Gaussian of phi_y(m), narrowed to float), so a kernel
+ * that walks rows for fixed columns can form it -- (float)(a0_row[n] * a0_col[j]), one
+ * double-precision product -- instead of reading it: 32 instead of 36 bytes per cell and
+ * double step.  Whether the product reproduces the stored float in EVERY cell depends on the
+ * factors' last bits, so it is checked, never assumed: slb_a0_factors_check() counts, for rows
+ * row_first .. row_first+nrows-1 and columns 0 .. ncols-1, the cells in which the two differ
+ * (bad[n] += count; device ints, cleared by the caller).  A caller enables the factored form
+ * only when every count is zero (host/slb_solver.c also tries neighbouring doubles as the row
+ * factor of a row that fails), and the lattices are then bit-identical by construction. */
+int slb_a0_factors_check(const float *a0, int pitch, int row_first, int nrows, int ncols,
+                         const double *a0_row, const double *a0_col, int *bad);
+
+/* slb_step_fused2_rows (rows_first/rows_second may both be NULL) with a0 formed from checked
+ * factors: a0_row has N+1 doubles, a0_col `pitch` doubles (16-byte aligned, local columns).
+ * The stored a0 is still passed: launches too narrow to fill the device go to the general
+ * kernel, which reads it. */
+int slb_step_fused2_factored(const slb_step2_geom *geom, const float *a0, const double *a0_row, const double *a0_col,
+                             const float *a_current, const float *b_current,
+                             const float *a_current_hs, const float *b_current_hs,
+                             const float *a_next, const float *b_next,
+                             const float *a_next_hs, const float *b_next_hs,
+                             float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
+                             const float cosines[8], float *rows_first, float *rows_second);
+
 /* Geometry of S = `steps` loop iterations in one launch (1 <= S <= 4): the
  * columns each of the 2S sweeps produces, in execution order (main sweep at t,
  * half-step sweep at t, main sweep at t+dt, ...). */
@@ -330,6 +356,9 @@ void  slb_pop_stream(void);
  *   38 = the four-column kernel also for launches too narrow to fill the device (which
  *   otherwise go to the general kernel with one column per lane), 39 = the schedule taken
  *   when the device's occupancy cannot be queried (every strip cut into chunks of rows).
+ *   slb_step_fused2_factored loads a0 like slb_step_fused2_rows unless asked otherwise (forming
+ *   it measured slower on MI355X): 50 = a0 formed from the factors once per row and handed from
+ *   stage to stage, 51 = every stage forms the a0 values of its own row.
  *   slb_step_multi: 32 / 33 / 34 = two columns per lane instead of four, with a
  *   register budget of 2 / 3 / 4 waves per SIMD; 35 / 36 / 37 = one column per lane, budget
  *   of 2 / 4 / 8 waves per SIMD.

@@ -28,7 +28,8 @@ ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "Handle
                  "slb_av_sums_exact", "slb_av_sums_exact_n", "slb_av_sums_exact_from_n", "slb_av_update_exact", "slb_halo_pack", "slb_halo_unpack", "slb_halo_pack_segs", "slb_halo_unpack_segs", "slb_av_partial",
                  "slb_frame_values", "slb_seq_sum", "slb_seq_sum_stats",
                  "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream", "slb_push_stream", "slb_pop_stream",
-                 "slb_set_tuning", "slb_version", "slb_static_init", "slb_av_static")
+                 "slb_set_tuning", "slb_version", "slb_static_init", "slb_av_static",
+                 "slb_a0_factors_check", "slb_step_fused2_factored")
 ABI_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha",
                "PhiYmin", "PhiYmax", "host_B", "t_start", "host_dPhi", "host_dt",
                "host_bdt", "host_nu_tilde", "host_nu2", "host_nu",
@@ -72,7 +73,8 @@ class SolverStruct(C.Structure):
                 ("G", C.c_int),
                 ("spare_a", C.c_void_p), ("spare_b", C.c_void_p), ("spare_ah", C.c_void_p),
                 ("spare_bh", C.c_void_p), ("spare_of", C.c_int), ("spare_of_hs", C.c_int),
-                ("stream", C.c_void_p), ("has_stream", C.c_int)]
+                ("stream", C.c_void_p), ("has_stream", C.c_int),
+                ("a0_row", C.c_void_p), ("a0_col", C.c_void_p), ("a0_rows_adjusted", C.c_int)]
 
 
 _lib = None
@@ -103,6 +105,9 @@ def lib():
         L.slb_step_fused2.restype = i
         L.slb_step_fused2_rows.argtypes = [C.POINTER(Step2Geom)] + [fp] * 13 + [C.POINTER(C.c_float * 8), fp, fp]
         L.slb_step_fused2_rows.restype = i
+        L.slb_step_fused2_factored.argtypes = [C.POINTER(Step2Geom)] + [fp] * 15 + [C.POINTER(C.c_float * 8), fp, fp]
+        L.slb_step_fused2_factored.restype = i
+        L.slb_a0_factors_check.argtypes, L.slb_a0_factors_check.restype = [fp, i, i, i, i, fp, fp, fp], i
         L.slb_step_multi.argtypes = [C.POINTER(MultiGeom), fp, C.POINTER(C.c_void_p * 4), C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p * 4), C.POINTER(C.c_float)]
         L.slb_step_multi.restype = i

@@ -407,6 +407,19 @@ __device__ __forceinline__ void widen(const float (&own)[4], float (&e)[6])
   e[5] = from_right_lane(own[0]);
 }
 
+#ifndef SLB_ADDR
+#define SLB_ADDR 0      // how the double step addresses memory: 0 plain pointers; 1 a scalar row pointer (forced through
+                        // v_readfirstlane) + a 32-bit lane offset: 2 spilled registers instead of 10, same speed
+#endif
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *p)
+{
+  const uint64_t u = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return reinterpret_cast<T *>(((uint64_t)hi << 32) | lo);
+}
+
 // DIAG: timing-only build of the point update (same memory accesses and lane exchanges,
 // two additions instead of the arithmetic); never used for results.
 template <bool DIAG, class Params>
@@ -619,6 +632,7 @@ struct Fused2Args {
   const float *p1a, *p1b, *p2a, *p2b;        // never-written cells of the in-between lattices
   float *a_o, *b_o, *a_ho, *b_ho;            // main lattice (t+2dt); half-step lattice (t+5dt/2)
   float *rows1, *rows2;                      // ROWS: [3][pitch] each: a rows 0, 1 and b row 1 of stage A's / C's output
+  const double *a0_row, *a0_col;             // A0F: a0[n][j] = (float)(a0_row[n] * a0_col[j]), see a0_factors_check_kernel
   float E_dc, E_omega, B, dt, dPhi, PhiYmin, nu, nu2, nu_tilde, bdt;
   float c[8];                                // cosines: stage A 0,1  B 2,3  C 4,5  D 6,7
   int N, pitch, m_offset, jj0;
@@ -642,7 +656,13 @@ struct Fused2Args {
 // in two pieces; marked non-temporal the pieces are written out 2-10 % faster (measured on
 // MI355X with this kernel and, without arithmetic, with scripts/membench.hip).  NTL: the same
 // mark on the loads -- slower, the halo lanes' re-reads then miss.
-template <int MINW, bool DIAG = false, bool ROWS = false, int H = 1, bool NTS = false, bool NTL = false>
+// A0F: the equilibrium coefficients are not read from memory but formed from their two factors,
+// a0[n][j] = (float)(a0_row[n] * a0_col[j]) in double arithmetic (one v_mul_f64 and one
+// v_cvt_f32_f64 per value): 4 of the 36 bytes per cell and launch less.  The caller has checked
+// cell by cell that this gives the bits of the stored a0 (slb_a0_factors_check).  1: a row's
+// values are formed once and handed from stage to stage like loaded ones; 2: every stage forms
+// the values of its own row (12 registers fewer, three times the double-precision work).
+template <int MINW, bool DIAG = false, bool ROWS = false, int H = 1, bool NTS = false, bool NTL = false, int A0F = 0>
 __global__ void __launch_bounds__(256, MINW)
 fused2_step_kernel(const Fused2Args p)
 {
@@ -709,15 +729,38 @@ fused2_step_kernel(const Fused2Args p)
 
   const size_t P = (size_t)p.pitch;
 
+  const unsigned jb = j * 4u;
+  (void)jb;
+  auto at_of = [&](const float *base, size_t row) -> const char * {
+#if SLB_ADDR == 1
+    return reinterpret_cast<const char *>(uniform_ptr(base + row)) + jb;
+#else
+    return reinterpret_cast<const char *>(base + row + j);
+#endif
+  };
   auto load4 = [&](const float *base, size_t row, float (&v)[V]) {
+    const char *at = at_of(base, row);
     if constexpr (NTL) {
       typedef float f4 __attribute__((ext_vector_type(4)));
-      const f4 q = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(base + row + j));
+      const f4 q = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(at));
       v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     } else {
-      const float4 q = *reinterpret_cast<const float4 *>(base + row + j);
+      const float4 q = *reinterpret_cast<const float4 *>(at);
       v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     }
+  };
+  auto store4 = [&](float *base, size_t row, const float (&v)[V]) {
+    float4 *at = reinterpret_cast<float4 *>(const_cast<char *>(at_of(base, row)));
+    if constexpr (NTS) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const f4 q = {v[0], v[1], v[2], v[3]};
+      __builtin_nontemporal_store(q, reinterpret_cast<f4 *>(at));
+    } else {
+      *at = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto store1 = [&](float *base, size_t row, int k, float x) {
+    reinterpret_cast<float *>(const_cast<char *>(at_of(base, row)))[k] = x;
   };
   // replace the columns a stage does not produce by the present contents of `pa`/`pb`
   auto keep_old = [&](const float *pa, const float *pb, size_t row, unsigned okbits,
@@ -757,11 +800,34 @@ fused2_step_kernel(const Fused2Args p)
   if (a_lo >= 1) { load4(p.a_h, (size_t)(a_lo - 1) * P, hA_p); load4(p.b_h, (size_t)(a_lo - 1) * P, hB_p); }
   load4(p.a_h, (size_t)a_lo * P, hA_c); load4(p.b_h, (size_t)a_lo * P, hB_c);
 
+  // A0F: this lane's column factors
+  double a0g[V] = {};
+  if constexpr (A0F != 0) {
+    const double2 g01 = *reinterpret_cast<const double2 *>(p.a0_col + j);
+    const double2 g23 = *reinterpret_cast<const double2 *>(p.a0_col + j + 2);
+    a0g[0] = g01.x; a0g[1] = g01.y; a0g[2] = g23.x; a0g[3] = g23.y;
+  }
+  auto a0_of_row = [&](int n, float (&v)[V]) {
+    if constexpr (A0F == 4) {                    // timing probe only: a0 neither read nor formed
+#pragma unroll
+      for (int k = 0; k < V; k++) v[k] = bphi[k];
+      return;
+    }
+    const double c = p.a0_row[n];                // wave-uniform
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      if constexpr (A0F == 3) v[k] = (float)a0g[k] * (float)c;      // timing probe only: not the reference's bits
+      else v[k] = (float)(a0g[k] * c);
+    }
+  };
+
   struct RowIn { float a0[V], ac[V], bc[V], hA[V], hB[V]; };
   auto load_row = [&](int r, RowIn &in) {
     const size_t row = (size_t)r * P;
-    load4(p.a0, row, in.a0); load4(p.a_c, row, in.ac); load4(p.b_c, row, in.bc);
+    if constexpr (A0F == 0) load4(p.a0, row, in.a0);
+    load4(p.a_c, row, in.ac); load4(p.b_c, row, in.bc);
     load4(p.a_h, row + P, in.hA); load4(p.b_h, row + P, in.hB);
+    if constexpr (A0F != 0) a0_of_row(r, in.a0);
   };
   RowIn cur = {};
 
@@ -780,8 +846,8 @@ fused2_step_kernel(const Fused2Args p)
 #pragma unroll
           for (int k = 0; k < V; k++) {
             if (flags & (1u << k)) {
-              p.rows1[(size_t)r * P + j + k] = o1A[k];
-              if (r == 1) p.rows1[2 * P + j + k] = o1B[k];
+              store1(p.rows1, (size_t)r * P, k, o1A[k]);
+              if (r == 1) store1(p.rows1, 2 * P, k, o1B[k]);
             }
           }
         }
@@ -794,7 +860,7 @@ fused2_step_kernel(const Fused2Args p)
         if (r == 1 && n0 == 0 && interior) {
 #pragma unroll
           for (int k = 0; k < V; k++) {
-            if (flags & (1u << k)) { p.rows1[P + j + k] = o1A[k]; p.rows1[2 * P + j + k] = o1B[k]; }
+            if (flags & (1u << k)) { store1(p.rows1, P, k, o1A[k]); store1(p.rows1, 2 * P, k, o1B[k]); }
           }
         }
       }
@@ -807,6 +873,7 @@ fused2_step_kernel(const Fused2Args p)
       float ea[6], eb[6], dla[V], dlb[V];
       widen(o1A, ea); widen(o1B, eb);
       diffs(o1A_pp, dla); diffs(o1B_pp, dlb);
+      if constexpr (A0F == 2) a0_of_row(rb, a0_1);
       stage(rb, s[2], s[3], a0_1, hA_p, hB_p, ea, eb, dla, dlb, o2A, o2B);
       if (need2) keep_old(p.p2a, p.p2b, (size_t)rb * P, flags >> 4, o2A, o2B);
     } else if (rb == p.N) {
@@ -820,18 +887,19 @@ fused2_step_kernel(const Fused2Args p)
       float ea[6], eb[6], dla[V], dlb[V];
       widen(o2A, ea); widen(o2B, eb);
       diffs(o2A_pp, dla); diffs(o2B_pp, dlb);
+      if constexpr (A0F == 2) a0_of_row(rc, a0_2);
       stage(rc, s[4], s[5], a0_2, o1A_pp, o1B_pp, ea, eb, dla, dlb, o3A, o3B);
       const size_t row = (size_t)rc * P;
       if (rc >= n0 && rc < n1) {
         if (wC_all) {
-          st4<NTS>(p.a_o + row, j, o3A);
-          if (rc > 0) st4<NTS>(p.b_o + row, j, o3B);
+          store4(p.a_o, row, o3A);
+          if (rc > 0) store4(p.b_o, row, o3B);
         } else {
 #pragma unroll
           for (int k = 0; k < V; k++) {
             if (flags & (1u << (12 + k))) {
-              p.a_o[row + j + k] = o3A[k];
-              if (rc > 0) p.b_o[row + j + k] = o3B[k];
+              store1(p.a_o, row, k, o3A[k]);
+              if (rc > 0) store1(p.b_o, row, k, o3B[k]);
             }
           }
         }
@@ -840,8 +908,8 @@ fused2_step_kernel(const Fused2Args p)
 #pragma unroll
             for (int k = 0; k < V; k++) {
               if (flags & (1u << (12 + k))) {
-                p.rows2[row + j + k] = o3A[k];
-                if (rc == 1) p.rows2[2 * P + j + k] = o3B[k];
+                store1(p.rows2, row, k, o3A[k]);
+                if (rc == 1) store1(p.rows2, 2 * P, k, o3B[k]);
               }
             }
           }
@@ -854,7 +922,7 @@ fused2_step_kernel(const Fused2Args p)
         if (rc == 1 && n0 == 0) {
 #pragma unroll
           for (int k = 0; k < V; k++) {
-            if (flags & (1u << (12 + k))) { p.rows2[P + j + k] = o3A[k]; p.rows2[2 * P + j + k] = o3B[k]; }
+            if (flags & (1u << (12 + k))) { store1(p.rows2, P, k, o3A[k]); store1(p.rows2, 2 * P, k, o3B[k]); }
           }
         }
       }
@@ -866,17 +934,18 @@ fused2_step_kernel(const Fused2Args p)
     widen(o3A, e3a); widen(o3B, e3b);
     if (rd >= n0 && rd < n1) {
       float o4A[V], o4B[V];
+      if constexpr (A0F == 2) a0_of_row(rd, a0_3);
       stage(rd, s[6], s[7], a0_3, o2A_pp, o2B_pp, e3a, e3b, d3A_pp, d3B_pp, o4A, o4B);
       const size_t row = (size_t)rd * P;
       if (wD_all) {
-        st4<NTS>(p.a_ho + row, j, o4A);
-        if (rd > 0) st4<NTS>(p.b_ho + row, j, o4B);
+        store4(p.a_ho, row, o4A);
+        if (rd > 0) store4(p.b_ho, row, o4B);
       } else {
 #pragma unroll
         for (int k = 0; k < V; k++) {
           if (flags & (1u << (16 + k))) {
-            p.a_ho[row + j + k] = o4A[k];
-            if (rd > 0) p.b_ho[row + j + k] = o4B[k];
+            store1(p.a_ho, row, k, o4A[k]);
+            if (rd > 0) store1(p.b_ho, row, k, o4B[k]);
           }
         }
       }
@@ -889,10 +958,30 @@ fused2_step_kernel(const Fused2Args p)
       d3A_p[k] = e3a[k + 2] - e3a[k]; d3B_p[k] = e3b[k + 2] - e3b[k];
       o2A_pp[k] = o2A_p[k]; o2B_pp[k] = o2B_p[k]; o2A_p[k] = o2A[k]; o2B_p[k] = o2B[k];
       o1A_pp[k] = o1A_p[k]; o1B_pp[k] = o1B_p[k]; o1A_p[k] = o1A[k]; o1B_p[k] = o1B[k];
-      a0_3[k] = a0_2[k]; a0_2[k] = a0_1[k]; a0_1[k] = cur.a0[k];
+      if constexpr (A0F != 2) { a0_3[k] = a0_2[k]; a0_2[k] = a0_1[k]; a0_1[k] = cur.a0[k]; }
       hA_p[k] = hA_c[k]; hB_p[k] = hB_c[k]; hA_c[k] = cur.hA[k]; hB_c[k] = cur.hB[k];
     }
   }
+}
+
+// Does (float)(a0_row[n] * a0_col[j]) -- the product and its narrowing as the double-step kernel
+// forms them -- give the stored a0[n][j], bit for bit?  bad[n] counts the cells of row n that
+// differ, for rows row0 .. row0+nrows-1 and columns 0 .. ncols-1.
+__global__ void __launch_bounds__(256)
+a0_factors_check_kernel(const float *a0, int pitch, int row0, int nrows, int ncols,
+                        const double *a0_row, const double *a0_col, int *bad)
+{
+  const int n = row0 + blockIdx.y;
+  if (n >= row0 + nrows) return;
+  const double c = a0_row[n];
+  int differ = 0;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ncols; j += gridDim.x * blockDim.x) {
+    const float formed = (float)(a0_col[j] * c);
+    differ += __float_as_uint(formed) != __float_as_uint(a0[(size_t)n * pitch + j]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) differ += __shfl_down(differ, off, 64);
+  if ((threadIdx.x & 63) == 0 && differ) atomicAdd(&bad[n], differ);
 }
 
 // ---------------------------------------------------------------------------
@@ -1719,7 +1808,7 @@ int resident_workgroups(K kernel, int block)
 // and only the groups left over are cut into chunks (`tail_chunk` rows, or shorter ones when
 // the lattice has few rounds); narrower lattices are cut into chunks of `tail_chunk` rows
 // throughout.
-template <int MINW, bool DIAG = false, bool ROWS = false, int H = 2, bool NTS = true, bool NTL = false>
+template <int MINW, bool DIAG = false, bool ROWS = false, int H = 2, bool NTS = true, bool NTL = false, int A0F = 0>
 int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
 {
   int lo = args.jf[0], hi = args.jl[0];
@@ -1731,7 +1820,7 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
   const int groups = (waves + wpb - 1) / wpb;
   auto chunks_of = [&](int len) { return (args.N + len - 1) / len; };
   // (tuning variant 39: as if the occupancy query had failed -- every strip is cut into chunks)
-  const int slots = n_chunk > 0 || g_variant == 39 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL>, block);
+  const int slots = n_chunk > 0 || g_variant == 39 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL, A0F>, block);
   // (measured on MI355X with two halo lanes and non-temporal stores: whole groups first wins
   // from one round of workgroups up -- 2.02 against 2.11 ms at 128 rows x 2^21 columns, 2.06
   // against 2.15 at 256 x 2^20, 0.53 against 0.57 at 64 x 2^20, 1.02-1.04 against 1.03-1.08 at
@@ -1762,7 +1851,7 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
     args.wg_begin[2] = args.wg_begin[1] + (groups - whole) * chunks_of(tail_chunk);
   }
   for (int k = args.n_phase; k < 3; k++) { args.g0[k] = 0; args.ng[k] = 1; args.len[k] = args.N; args.wg_begin[k + 1] = args.wg_begin[k]; }
-  hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL>), dim3(args.wg_begin[args.n_phase]), dim3(block), 0,
+  hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL, A0F>), dim3(args.wg_begin[args.n_phase]), dim3(block), 0,
                      launch_stream(), args);
   return (int)hipGetLastError();
 }
@@ -1963,6 +2052,14 @@ int slb_step_fused2(const slb_step2_geom *g, const float *a0,
                               a_next_hs, b_next_hs, a_out, b_out, a_out_hs, b_out_hs, cosines, nullptr, nullptr);
 }
 
+static int step_fused2_impl(const slb_step2_geom *g, const float *a0, const double *a0_row, const double *a0_col,
+                            const float *a_current, const float *b_current,
+                            const float *a_current_hs, const float *b_current_hs,
+                            const float *a_next, const float *b_next,
+                            const float *a_next_hs, const float *b_next_hs,
+                            float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
+                            const float cosines[8], float *rows_first, float *rows_second);
+
 int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
                          const float *a_current, const float *b_current,
                          const float *a_current_hs, const float *b_current_hs,
@@ -1970,6 +2067,49 @@ int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
                          const float *a_next_hs, const float *b_next_hs,
                          float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
                          const float cosines[8], float *rows_first, float *rows_second)
+{
+  return step_fused2_impl(g, a0, nullptr, nullptr, a_current, b_current, a_current_hs, b_current_hs, a_next, b_next,
+                          a_next_hs, b_next_hs, a_out, b_out, a_out_hs, b_out_hs, cosines, rows_first, rows_second);
+}
+
+int slb_step_fused2_factored(const slb_step2_geom *g, const float *a0, const double *a0_row, const double *a0_col,
+                             const float *a_current, const float *b_current,
+                             const float *a_current_hs, const float *b_current_hs,
+                             const float *a_next, const float *b_next,
+                             const float *a_next_hs, const float *b_next_hs,
+                             float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
+                             const float cosines[8], float *rows_first, float *rows_second)
+{
+  if (!a0_row || !a0_col || !aligned16(a0_col)) {
+    fprintf(stderr, "slb_step_fused2_factored: the two factor arrays are needed, the column factors 16-byte aligned\n");
+    return -1;
+  }
+  return step_fused2_impl(g, a0, a0_row, a0_col, a_current, b_current, a_current_hs, b_current_hs, a_next, b_next,
+                          a_next_hs, b_next_hs, a_out, b_out, a_out_hs, b_out_hs, cosines, rows_first, rows_second);
+}
+
+int slb_a0_factors_check(const float *a0, int pitch, int row_first, int nrows, int ncols,
+                         const double *a0_row, const double *a0_col, int *bad)
+{
+  if (!a0 || !a0_row || !a0_col || !bad || pitch < 1 || row_first < 0 || nrows < 0 || ncols < 0 || ncols > pitch) {
+    fprintf(stderr, "slb_a0_factors_check: bad arguments\n");
+    return -1;
+  }
+  if (nrows == 0 || ncols == 0) return 0;
+  int bx = (ncols + 255) / 256;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(a0_factors_check_kernel, dim3(bx, nrows), dim3(256), 0, launch_stream(), a0, pitch, row_first, nrows,
+                     ncols, a0_row, a0_col, bad);
+  return (int)hipGetLastError();
+}
+
+static int step_fused2_impl(const slb_step2_geom *g, const float *a0, const double *a0_row, const double *a0_col,
+                            const float *a_current, const float *b_current,
+                            const float *a_current_hs, const float *b_current_hs,
+                            const float *a_next, const float *b_next,
+                            const float *a_next_hs, const float *b_next_hs,
+                            float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
+                            const float cosines[8], float *rows_first, float *rows_second)
 {
   if ((rows_first == nullptr) != (rows_second == nullptr)) {
     fprintf(stderr, "slb_step_fused2_rows: both row buffers or neither\n");
@@ -1997,6 +2137,7 @@ int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
   s.p1a = a_next; s.p1b = b_next; s.p2a = a_next_hs; s.p2b = b_next_hs;
   s.a_o = a_out; s.b_o = b_out; s.a_ho = a_out_hs; s.b_ho = b_out_hs;
   s.rows1 = rows_first; s.rows2 = rows_second;
+  s.a0_row = a0_row; s.a0_col = a0_col;
   s.E_dc = g_phys.E_dc; s.E_omega = g_phys.E_omega; s.B = g_phys.B; s.dt = g_phys.dt;
   s.dPhi = g_phys.dPhi; s.PhiYmin = g_phys.PhiYmin; s.nu = g_phys.nu; s.nu2 = g_phys.nu2;
   s.nu_tilde = g_phys.nu_tilde; s.bdt = g_phys.bdt;
@@ -2045,6 +2186,23 @@ int slb_step_fused2_rows(const slb_step2_geom *g, const float *a0,
   }
   // tuning variant 26: every strip group cut into chunks, as for a narrow lattice
   int n_chunk = g_n_chunk > 0 ? g_n_chunk : (g_variant == 26 || s.N < 64 ? tail_chunk : 0);
+  // a0 formed from its factors instead of loaded: tuning variants 50 (a row's values formed once
+  // and handed from stage to stage) and 51 (every stage forms its own row's).  Not the default:
+  // measured on MI355X at 128 x 2^20 the launch takes 1.19-1.21 ms with a0 formed against 1.02-1.04
+  // with a0 loaded, although it moves 32 instead of 36 bytes per cell -- and 1.08 ms with a0
+  // neither loaded nor formed (a timing probe), so it is the schedule of the row loop that the
+  // change upsets, not the double-precision products (profiles/r03/a0_factored_ab.txt).
+  if (a0_row && (g_variant == 50 || g_variant == 51 || g_variant == 53 || g_variant == 54)) {
+    if (g_variant == 51)
+      return rows_first ? launch_fused2<3, false, true, 2, true, false, 2>(s, block, n_chunk, tail_chunk)
+                        : launch_fused2<3, false, false, 2, true, false, 2>(s, block, n_chunk, tail_chunk);
+#ifdef SLB_TIMING_VARIANTS
+    if (g_variant == 53) return launch_fused2<3, false, false, 2, true, false, 3>(s, block, n_chunk, tail_chunk);
+    if (g_variant == 54) return launch_fused2<3, false, false, 2, true, false, 4>(s, block, n_chunk, tail_chunk);
+#endif
+    return rows_first ? launch_fused2<3, false, true, 2, true, false, 1>(s, block, n_chunk, tail_chunk)
+                      : launch_fused2<3, false, false, 2, true, false, 1>(s, block, n_chunk, tail_chunk);
+  }
   if (rows_first) return launch_fused2<3, false, true>(s, block, n_chunk, tail_chunk);
   // default: two halo lanes per side (the 60 interior lanes' stores start on 64-byte boundaries),
   // non-temporal stores, registers for 3 waves per SIMD.  The rest are tuning variants.

@@ -63,6 +63,12 @@ struct slb_solver {
    * the calling thread's launches go (slb_push_stream / slb_set_stream) */
   void *stream;
   int   has_stream;
+  /* a0 in separable form, for the double step (slb_step_fused2_factored): device doubles,
+   * N+1 row factors and `pitch` column factors, both NULL unless (float)(row * column) was
+   * checked to give the stored a0 in every cell.  a0_rows_adjusted: rows whose factor had to
+   * be moved to a neighbouring double for that; -1: the check failed, a0 is loaded. */
+  double *a0_row, *a0_col;
+  int   a0_rows_adjusted;
 };
 
 /* Allocate the slab of rank `rank` of `nranks`, build a0 for its columns

@@ -87,20 +87,85 @@ static float phi_y_of(int m) { return PhiYmin + host_dPhi * (m - 1); }
 /* Equilibrium coefficients for global columns m_offset .. m_offset+cols-1
  * (reference: src/boltzmann_solver.c:119-126).  exp(-mu*phi_y^2/2) depends on
  * the column only and is evaluated once per column in long double; the
- * reference's product (float coefficient) x (long double expl) -> float is kept. */
-static void fill_a0(float *h, int pitch, int m_offset, int cols)
+ * reference's product (float coefficient) x (long double expl) -> float is kept.
+ * rowf / colf (may be NULL): the two factors as doubles, N+1 and `cols` of them. */
+static void fill_a0(float *h, int pitch, int m_offset, int cols, double *rowf, double *colf)
 {
   long double *gauss = (long double *)malloc(sizeof(long double) * (size_t)cols);
-  for (int j = 0; j < cols; j++)
+  for (int j = 0; j < cols; j++) {
     gauss[j] = expl(-host_mu * pow(phi_y_of(m_offset + j), 2) / 2);
+    if (colf) colf[j] = (double)gauss[j];
+  }
   const double i0 = slb_bessel_In(0, host_mu);
   for (int n = 0; n <= host_N; n++) {
     const float c = slb_bessel_In(n, host_mu) * (n == 0 ? 0.5 : 1) / (SLB_PI * i0)
                     * sqrt(host_mu / (2 * SLB_PI * host_alpha));
+    if (rowf) rowf[n] = (double)c;
     float *row = h + (size_t)n * pitch;
     for (int j = 0; j < cols; j++) row[j] = c * gauss[j];
   }
   free(gauss);
+}
+
+/* a0 in separable form for the double-step kernel: the factors go to the device, the kernel's
+ * own product is compared with the stored a0 in every cell, and a row with a cell that differs
+ * (the double product was rounded once more than the reference's long double one) gets the
+ * neighbouring doubles tried as its factor.  Only when every cell of every row agrees do the
+ * factors stay; otherwise a0 is loaded as before.  SLB_A0=load skips all this. */
+static void factor_a0(slb_solver *s, const double *rowf, const double *colf, int cols)
+{
+  const char *mode = getenv("SLB_A0");
+  s->a0_row = s->a0_col = NULL;
+  s->a0_rows_adjusted = -1;
+  if (mode && strcmp(mode, "load") == 0) return;
+  const int rows = s->N + 1;
+  int *bad = NULL, *h_bad = (int *)malloc(sizeof(int) * (size_t)rows);
+  double *colp = (double *)calloc((size_t)s->pitch, sizeof(double));
+  if (!h_bad || !colp) { free(h_bad); free(colp); return; }
+  memcpy(colp, colf, sizeof(double) * (size_t)cols);
+  HIP_OK(hipMalloc((void **)&s->a0_row, sizeof(double) * (size_t)rows));
+  HIP_OK(hipMalloc((void **)&s->a0_col, sizeof(double) * (size_t)s->pitch));
+  HIP_OK(hipMalloc((void **)&bad, sizeof(int) * (size_t)rows));
+  HIP_OK(hipMemcpy(s->a0_row, rowf, sizeof(double) * (size_t)rows, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(s->a0_col, colp, sizeof(double) * (size_t)s->pitch, hipMemcpyHostToDevice));
+  HIP_OK(hipMemset(bad, 0, sizeof(int) * (size_t)rows));
+  free(colp);
+  /* (the check runs on the caller's launch stream, the copies on the null stream: whole-device
+   * waits keep them in order whatever kind of stream that is; this is set-up, not the loop) */
+  HIP_OK(hipDeviceSynchronize());
+  int ok = slb_a0_factors_check(s->a0, s->pitch, 0, rows, cols, s->a0_row, s->a0_col, bad) == 0;
+  HIP_OK(hipDeviceSynchronize());
+  if (ok) HIP_OK(hipMemcpy(h_bad, bad, sizeof(int) * (size_t)rows, hipMemcpyDeviceToHost));
+  int adjusted = 0;
+  for (int n = 0; ok && n < rows; n++) {
+    if (h_bad[n] == 0) continue;
+    /* the doubles next to the factor, nearest first, on both sides */
+    int fixed = 0;
+    double up = rowf[n], down = rowf[n];
+    for (int k = 0; k < 32 && !fixed; k++) {
+      up = nextafter(up, INFINITY); down = nextafter(down, -INFINITY);
+      const double cand[2] = {up, down};
+      for (int q = 0; q < 2 && !fixed; q++) {
+        int count = 0;
+        HIP_OK(hipMemcpy(s->a0_row + n, &cand[q], sizeof(double), hipMemcpyHostToDevice));
+        HIP_OK(hipMemset(bad + n, 0, sizeof(int)));
+        HIP_OK(hipDeviceSynchronize());
+        if (slb_a0_factors_check(s->a0, s->pitch, n, 1, cols, s->a0_row, s->a0_col, bad) != 0) { ok = 0; break; }
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemcpy(&count, bad + n, sizeof(int), hipMemcpyDeviceToHost));
+        fixed = count == 0;
+      }
+    }
+    if (!fixed) ok = 0; else adjusted++;
+  }
+  HIP_OK(hipFree(bad));
+  free(h_bad);
+  if (!ok) {
+    HIP_OK(hipFree(s->a0_row)); HIP_OK(hipFree(s->a0_col));
+    s->a0_row = s->a0_col = NULL;
+    return;
+  }
+  s->a0_rows_adjusted = adjusted;
 }
 
 slb_solver *slb_solver_create(int rank, int nranks)
@@ -143,11 +208,16 @@ slb_solver *slb_solver_create(int rank, int nranks)
   const size_t bytes = cells * sizeof(float);
   float *h = (float *)calloc(cells, sizeof(float));
   if (!h) { fprintf(stderr, "slb_solver_create: out of host memory\n"); free(s); return NULL; }
-  fill_a0(h, s->pitch, s->m_offset, cols);
+  double *rowf = (double *)malloc(sizeof(double) * (size_t)(s->N + 1));
+  double *colf = (double *)malloc(sizeof(double) * (size_t)cols);
+  if (!rowf || !colf) { fprintf(stderr, "slb_solver_create: out of host memory\n"); free(h); free(rowf); free(colf); free(s); return NULL; }
+  fill_a0(h, s->pitch, s->m_offset, cols, rowf, colf);
 
   HIP_OK(lattice_alloc(&s->a0, bytes));
   HIP_OK(hipMemcpy(s->a0, h, bytes, hipMemcpyHostToDevice));
   free(h);
+  factor_a0(s, rowf, colf, cols);
+  free(rowf); free(colf);
   for (int i = 0; i < 4; i++) {
     HIP_OK(lattice_alloc(&s->a[i], bytes));
     HIP_OK(lattice_alloc(&s->b[i], bytes));
@@ -172,6 +242,7 @@ void slb_solver_destroy(slb_solver *s)
   lattice_free(s->a0);
   for (int i = 0; i < 4; i++) { lattice_free(s->a[i]); lattice_free(s->b[i]); }
   hipFree(s->av_data); hipFree(s->sums); hipFree(s->halo_buf);
+  if (s->a0_row) { hipFree(s->a0_row); hipFree(s->a0_col); }
   lattice_free(s->spare_a); lattice_free(s->spare_b); lattice_free(s->spare_ah); lattice_free(s->spare_bh);
   free(s);
 }
@@ -373,11 +444,19 @@ void slb_solver_double_step_range_rows(slb_solver *s, int j_first, int j_last, c
     g.j_first[q] = g.j_first[q + 1] - 1 > lo[q] ? g.j_first[q + 1] - 1 : lo[q];
     g.j_last[q]  = g.j_last[q + 1] + 1 < hi[q] ? g.j_last[q + 1] + 1 : hi[q];
   }
-  { int rc_; ON(s, rc_ = slb_step_fused2_rows(&g, s->a0, s->a[s->current], s->b[s->current],
+  if (s->a0_row) {
+    int rc_; ON(s, rc_ = slb_step_fused2_factored(&g, s->a0, s->a0_row, s->a0_col, s->a[s->current], s->b[s->current],
                                    s->a[s->current_hs], s->b[s->current_hs],
                                    s->a[s->next], s->b[s->next], s->a[s->next_hs], s->b[s->next_hs],
                                    s->spare_a, s->spare_b, s->spare_ah, s->spare_bh, c,
-                                   rows_first, rows_second)); check_sweep(rc_, __LINE__); }
+                                   rows_first, rows_second)); check_sweep(rc_, __LINE__);
+  } else {
+    int rc_; ON(s, rc_ = slb_step_fused2_rows(&g, s->a0, s->a[s->current], s->b[s->current],
+                                   s->a[s->current_hs], s->b[s->current_hs],
+                                   s->a[s->next], s->b[s->next], s->a[s->next_hs], s->b[s->next_hs],
+                                   s->spare_a, s->spare_b, s->spare_ah, s->spare_bh, c,
+                                   rows_first, rows_second)); check_sweep(rc_, __LINE__);
+  }
 }
 
 /* after two iterations the ping-pong indices are back where they were; the

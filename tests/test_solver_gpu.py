@@ -334,7 +334,7 @@ def test_double_step_bit_exact(slb, oracle, N, M, B, omega, pairs, n_chunk):
     L = slb.lib()
     try:
         sol.tiptoe()
-        for variant in (0, 20, 21, 23, 24, 25, 26, 27, 29, 30, 34, 38, 39):
+        for variant in (0, 20, 21, 23, 24, 25, 26, 27, 29, 30, 34, 38, 39, 50, 51):
             L.slb_set_tuning(variant, n_chunk, 0)
             for _ in range(pairs):
                 sol.double_step()
@@ -435,6 +435,65 @@ def test_double_step_hands_out_the_rows_av_reads(slb, oracle, N, M, B, omega):
     finally:
         sol.close()
         orc.close()
+
+
+@pytest.mark.parametrize("N,M,mu", [(32, 4096, 5.0), (128, 300001, 5.0), (64, 70001, 0.7), (24, 5003, 31.0)])
+def test_a0_from_its_factors_is_checked_cell_by_cell(slb, oracle, N, M, mu):
+    """The double step forms a0 from a row factor and a column factor only after every cell of
+    the lattice was compared with the stored a0 (reference: src/boltzmann_c_solver.c:117-122 is
+    a float coefficient times a long-double Gaussian).  Here: the engine's check passed (rows
+    whose factor had to move to a neighbouring double are counted), the stored a0 is the
+    oracle's, the check kernel does find a factor that is off by parts in 1e9, and the double
+    step with a0 loaded (default), formed once per row (50) and formed per stage (51) all leave
+    the oracle's lattices."""
+    import torch
+    p = oracle.make_params(N=N, M=M, B=0.3, omega=20.0, mu=mu)
+    slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    L = slb.lib()
+    orc = oracle.OracleState(p)
+    sol = slb.Solver()
+    try:
+        s = sol.s
+        assert s.a0_row and s.a0_col and 0 <= s.a0_rows_adjusted <= N + 1
+        assert np.array_equal(sol.rows(0)[:, :M + 3].view(np.uint32), orc.array("a0").view(np.uint32))
+        bad = torch.zeros(N + 1, dtype=torch.int32, device="cuda")
+        assert L.slb_a0_factors_check(s.a0, s.pitch, 0, N + 1, M + 3, s.a0_row, s.a0_col, bad.data_ptr()) == 0
+        torch.cuda.synchronize()
+        assert int(bad.sum()) == 0
+        # a row factor that is slightly off is caught
+        fac = _device_doubles(torch, s.a0_row, N + 1)
+        wrong = fac.clone()
+        wrong[1] *= 1.0 + 1e-9
+        bad.zero_()
+        assert L.slb_a0_factors_check(s.a0, s.pitch, 0, N + 1, M + 3, wrong.data_ptr(), s.a0_col, bad.data_ptr()) == 0
+        torch.cuda.synchronize()
+        counts = bad.cpu().numpy()
+        assert counts[1] > 0 and counts[0] == 0 and counts[2:].sum() == 0
+        sol.tiptoe()
+        for variant in (50, 51, 0):
+            L.slb_set_tuning(variant, 0, 0)
+            sol.double_step()
+            sol.double_step()
+            orc.step(4)
+            _compare_live_state(sol, orc, M)
+    finally:
+        L.slb_set_tuning(0, 0, 0)
+        sol.close()
+        orc.close()
+
+
+def _device_doubles(torch, ptr, n):
+    """n doubles at device address `ptr` as a new CUDA tensor (copied with the HIP runtime)."""
+    import ctypes
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    with open("/proc/self/maps") as f:
+        paths = sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    hip = ctypes.CDLL(paths[0])
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert hip.hipMemcpy(out.data_ptr(), ptr, 8 * n, 3) == 0          # hipMemcpyDeviceToDevice
+    torch.cuda.synchronize()
+    return out
 
 
 @pytest.mark.parametrize("M", [30000, 31000])        # 125 and 130 waves of 240 columns, four chunks of rows each
