@@ -198,6 +198,14 @@ int slb_step_fused2_factored(const slb_step2_geom *geom, const float *a0, const 
                              float *a_out, float *b_out, float *a_out_hs, float *b_out_hs,
                              const float cosines[8], float *rows_first, float *rows_second);
 
+/* Self-test of the shared-reciprocal division the tuned kernels use for the two quotients of
+ * a point (same denominator): `count` pseudo-random triples (two numerators over every bit
+ * pattern -- denormals, zeros, infinities, NaN included -- and a denominator between 0.5 and
+ * 2^100, the range the kernels use it in) are divided both ways on the GPU; *differ (device, cleared by the caller) receives the
+ * number of quotients whose bits differ from the compiler's IEEE division, first_bad (device,
+ * 4 floats) the first such numerator, denominator and the two results. */
+int slb_selftest_division(unsigned long long count, unsigned seed, unsigned long long *differ, float *first_bad);
+
 /* Geometry of S = `steps` loop iterations in one launch (1 <= S <= 4): the
  * columns each of the 2S sweeps produces, in execution order (main sweep at t,
  * half-step sweep at t, main sweep at t+dt, ...). */
@@ -356,6 +364,8 @@ void  slb_pop_stream(void);
  *   38 = the four-column kernel also for launches too narrow to fill the device (which
  *   otherwise go to the general kernel with one column per lane), 39 = the schedule taken
  *   when the device's occupancy cannot be queried (every strip cut into chunks of rows).
+ *   60 = the point update with the row-dependent factors taken out of the general rows and dt*a0
+ *   handed from stage to stage, 61 = 60 with the two quotients of a point sharing one reciprocal.
  *   slb_step_fused2_factored loads a0 like slb_step_fused2_rows unless asked otherwise (forming
  *   it measured slower on MI355X): 50 = a0 formed from the factors once per row and handed from
  *   stage to stage, 51 = every stage forms the a0 values of its own row.

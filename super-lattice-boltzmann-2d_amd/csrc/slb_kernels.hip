@@ -436,6 +436,126 @@ __device__ __forceinline__ void point_update_sel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same point update with fewer instructions, bit for bit the same results.
+//
+// div2_shared: the two quotients of a point have the same denominator xi = nu^2 + mu_t1^2.  The
+// compiler's IEEE division is, per quotient: scale numerator and denominator (v_div_scale x 2),
+// reciprocal (v_rcp, quarter rate), two fused steps to refine it, the quotient and two
+// correction steps, v_div_fmas, v_div_fixup.  v_div_scale leaves a denominator alone unless it
+// is denormal, at least 2^126, 2^96 times smaller than the numerator, or small together with a
+// tiny numerator -- none of which happens for 0.5 <= xi <= 2^100 (the launcher checks nu^2 and
+// the largest mu_t1 a run can form, and takes the plain division otherwise) -- so the refined
+// reciprocal is formed once, from xi itself, and serves both quotients.  A numerator is still
+// scaled by the hardware (v_div_scale: 2^64 up when the quotient would be tiny), and
+// v_div_fmas is told so (its flag is "the numerator was changed"), then v_div_fixup for
+// zeros, infinities and NaN as usual: 19 vector instructions and one reciprocal for both
+// quotients instead of 22 and two.  slb_selftest_division compares it with `/` on the GPU.
+//
+// Row-dependent factors: the reference multiplies the n-1 terms by 0 at n < 2 (n = 0 for the
+// other array) and by 2 at n = 1.  Those rows are the first two of 2^7 and more, and n is the
+// same for the whole wave: the caller patches the two differences under a branch that only
+// rows 0 and 1 take, so the other rows spend no instruction on it (1.0f * x is x itself).
+//
+// dta0: dt * a0 is the same product in every stage a row passes through; it is formed when
+// the row is loaded and handed on instead of a0.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void div2_shared(float n1, float n2, float d, float &q1, float &q2)
+{
+  const float y0 = __builtin_amdgcn_rcpf(d);
+  const float e  = __builtin_fmaf(-d, y0, 1.0f);
+  const float y  = __builtin_fmaf(e, y0, y0);
+  auto quotient = [&](float n) {
+    bool hw_flag;
+    const float ns = __builtin_amdgcn_div_scalef(n, d, true, &hw_flag);
+    const bool scaled = ns != n;            // (the hardware's flag also fires for numerators beyond 2^96 x d,
+                                            //  for which it would have scaled the denominator instead)
+    const float qa = ns * y;
+    const float ra = __builtin_fmaf(-d, qa, ns);
+    const float qb = __builtin_fmaf(ra, y, qa);
+    const float rb = __builtin_fmaf(-d, qb, ns);
+    const float qc = __builtin_amdgcn_div_fmasf(rb, y, qb, scaled);
+    return __builtin_amdgcn_div_fixupf(qc, d, n);
+  };
+  q1 = quotient(n1);
+  q2 = quotient(n2);
+}
+
+// dta0v: dt * a0;  loA: chi * [n >= 1] (A[n-1][m+1] - A[n-1][m-1]);  loB: [n >= 2] (B[n-1][m+1] - B[n-1][m-1])
+template <bool DIV2, class Params>
+__device__ __forceinline__ void point_update_fast(
+    const Params &p, float fn, float mu_part, float mu1_part,
+    float dta0v, float ac, float bc, float Ap, float Am, float Bp, float Bm,
+    float loA, float loB, float &a_new, float &b_new)
+{
+  const float mu_t  = fn * mu_part;
+  const float mu_t1 = fn * mu1_part;
+  const float sb = (Bp - Bm) - loB;
+  const float g  = ((dta0v + ac * p.nu_tilde) - bc * mu_t) + p.bdt * sb;
+  const float sa = (loA - Ap) + Am;
+  const float h  = (bc * p.nu_tilde + ac * mu_t) + p.bdt * sa;
+  const float xi = p.nu2 + mu_t1 * mu_t1;
+  const float na = g * p.nu - h * mu_t1, nb = g * mu_t1 + h * p.nu;
+  if constexpr (DIV2) {
+    div2_shared(na, nb, xi, a_new, b_new);
+  } else {
+    a_new = na / xi;
+    b_new = nb / xi;
+  }
+}
+
+// Two adjacent columns at a time, spelled with two-element vectors so that every operation is
+// one packed instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: separately rounded per
+// element, like their scalar forms) whatever the optimiser would have paired on its own -- in
+// particular the fused steps of the division, which it never pairs.
+typedef float slb_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ slb_f2 fma2(slb_f2 a, slb_f2 b, slb_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ void div2_shared_pair(slb_f2 n1, slb_f2 n2, slb_f2 d, slb_f2 &q1, slb_f2 &q2)
+{
+  const slb_f2 y0 = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const slb_f2 one = {1.0f, 1.0f};
+  const slb_f2 e = fma2(-d, y0, one);
+  const slb_f2 y = fma2(e, y0, y0);
+  auto quotient = [&](slb_f2 n) {
+    bool hw_flag;
+    const slb_f2 ns = {__builtin_amdgcn_div_scalef(n.x, d.x, true, &hw_flag), __builtin_amdgcn_div_scalef(n.y, d.y, true, &hw_flag)};
+    const bool scaled_x = ns.x != n.x, scaled_y = ns.y != n.y;
+    const slb_f2 qa = ns * y;
+    const slb_f2 ra = fma2(-d, qa, ns);
+    const slb_f2 qb = fma2(ra, y, qa);
+    const slb_f2 rb = fma2(-d, qb, ns);
+    const float cx = __builtin_amdgcn_div_fmasf(rb.x, y.x, qb.x, scaled_x);
+    const float cy = __builtin_amdgcn_div_fmasf(rb.y, y.y, qb.y, scaled_y);
+    const slb_f2 q = {__builtin_amdgcn_div_fixupf(cx, d.x, n.x), __builtin_amdgcn_div_fixupf(cy, d.y, n.y)};
+    return q;
+  };
+  q1 = quotient(n1);
+  q2 = quotient(n2);
+}
+
+template <bool DIV2, class Params>
+__device__ __forceinline__ void point_update_pair(
+    const Params &p, float fn, slb_f2 mu_part, slb_f2 mu1_part,
+    slb_f2 dta0v, slb_f2 ac, slb_f2 bc, slb_f2 Ap, slb_f2 Am, slb_f2 Bp, slb_f2 Bm,
+    slb_f2 loA, slb_f2 loB, slb_f2 &a_new, slb_f2 &b_new)
+{
+  const slb_f2 mu_t  = fn * mu_part;
+  const slb_f2 mu_t1 = fn * mu1_part;
+  const slb_f2 sb = (Bp - Bm) - loB;
+  const slb_f2 g  = ((dta0v + ac * p.nu_tilde) - bc * mu_t) + p.bdt * sb;
+  const slb_f2 sa = (loA - Ap) + Am;
+  const slb_f2 h  = (bc * p.nu_tilde + ac * mu_t) + p.bdt * sa;
+  const slb_f2 xi = p.nu2 + mu_t1 * mu_t1;
+  const slb_f2 na = g * p.nu - h * mu_t1, nb = g * mu_t1 + h * p.nu;
+  if constexpr (DIV2) {
+    div2_shared_pair(na, nb, xi, a_new, b_new);
+  } else {
+    a_new = na / xi;
+    b_new = nb / xi;
+  }
+}
+
 template <bool NT, int MINW, bool DIAG = false, bool NTS = NT>
 __global__ void __launch_bounds__(256, MINW)
 fused_step_kernel(const FusedArgs p)
@@ -662,7 +782,9 @@ struct Fused2Args {
 // cell by cell that this gives the bits of the stored a0 (slb_a0_factors_check).  1: a row's
 // values are formed once and handed from stage to stage like loaded ones; 2: every stage forms
 // the values of its own row (12 registers fewer, three times the double-precision work).
-template <int MINW, bool DIAG = false, bool ROWS = false, int H = 1, bool NTS = false, bool NTL = false, int A0F = 0>
+// OPT (bits): 1 = point_update_fast (row-dependent factors patched under a wave-uniform branch,
+// dt * a0 carried instead of a0), 2 = also div2_shared.  Same bits as OPT = 0.
+template <int MINW, bool DIAG = false, bool ROWS = false, int H = 1, bool NTS = false, bool NTL = false, int A0F = 0, int OPT = 0>
 __global__ void __launch_bounds__(256, MINW)
 fused2_step_kernel(const Fused2Args p)
 {
@@ -776,11 +898,42 @@ fused2_step_kernel(const Fused2Args p)
                    const float (&upa)[6], const float (&upb)[6], const float (&dla)[V], const float (&dlb)[V],
                    float (&oa)[V], float (&ob)[V]) {
     const float fn = (float)n;
+    if constexpr (OPT == 0 || DIAG) {
 #pragma unroll
-    for (int k = 0; k < V; k++) {
-      const float mu_a = (sa + bphi[k]) * p.dt / 2.0f, mu_b = (sb + bphi[k]) * p.dt / 2.0f;
-      point_update_sel<DIAG>(p, n, fn, mu_a, mu_b, a0v[k], ca[k], cb[k],
-                             upa[k + 2], upa[k], upb[k + 2], upb[k], dla[k], dlb[k], oa[k], ob[k]);
+      for (int k = 0; k < V; k++) {
+        const float mu_a = (sa + bphi[k]) * p.dt / 2.0f, mu_b = (sb + bphi[k]) * p.dt / 2.0f;
+        point_update_sel<DIAG>(p, n, fn, mu_a, mu_b, a0v[k], ca[k], cb[k],
+                               upa[k + 2], upa[k], upb[k + 2], upb[k], dla[k], dlb[k], oa[k], ob[k]);
+      }
+    } else {
+      float la[V], lb[V];
+#pragma unroll
+      for (int k = 0; k < V; k++) { la[k] = dla[k]; lb[k] = dlb[k]; }
+      if (n < 2) {                               // the same for the whole wave; rows 0 and 1 only
+        asm volatile("" ::);                     // (keeps this a branch: as selects it would cost every row)
+#pragma unroll
+        for (int k = 0; k < V; k++) { lb[k] = 0.0f; la[k] = n == 0 ? 0.0f : 2.0f * la[k]; }
+      }
+      if constexpr ((OPT & 4) != 0) {
+#pragma unroll
+        for (int k = 0; k < V; k += 2) {
+          const slb_f2 bp = {bphi[k], bphi[k + 1]};
+          const slb_f2 mu_a = (sa + bp) * p.dt / 2.0f, mu_b = (sb + bp) * p.dt / 2.0f;
+          slb_f2 qa, qb;
+          point_update_pair<(OPT & 2) != 0>(p, fn, mu_a, mu_b, slb_f2{a0v[k], a0v[k + 1]}, slb_f2{ca[k], ca[k + 1]},
+                                            slb_f2{cb[k], cb[k + 1]}, slb_f2{upa[k + 2], upa[k + 3]}, slb_f2{upa[k], upa[k + 1]},
+                                            slb_f2{upb[k + 2], upb[k + 3]}, slb_f2{upb[k], upb[k + 1]},
+                                            slb_f2{la[k], la[k + 1]}, slb_f2{lb[k], lb[k + 1]}, qa, qb);
+          oa[k] = qa.x; oa[k + 1] = qa.y; ob[k] = qb.x; ob[k + 1] = qb.y;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+          const float mu_a = (sa + bphi[k]) * p.dt / 2.0f, mu_b = (sb + bphi[k]) * p.dt / 2.0f;
+          point_update_fast<(OPT & 2) != 0>(p, fn, mu_a, mu_b, a0v[k], ca[k], cb[k],
+                                            upa[k + 2], upa[k], upb[k + 2], upb[k], la[k], lb[k], oa[k], ob[k]);
+        }
+      }
     }
   };
   auto diffs = [&](const float (&own)[V], float (&d)[V]) {
@@ -828,6 +981,10 @@ fused2_step_kernel(const Fused2Args p)
     load4(p.a_c, row, in.ac); load4(p.b_c, row, in.bc);
     load4(p.a_h, row + P, in.hA); load4(p.b_h, row + P, in.hB);
     if constexpr (A0F != 0) a0_of_row(r, in.a0);
+    if constexpr (OPT != 0 && !DIAG) {
+#pragma unroll
+      for (int k = 0; k < V; k++) in.a0[k] = p.dt * in.a0[k];     // handed on as dt * a0
+    }
   };
   RowIn cur = {};
 
@@ -982,6 +1139,46 @@ a0_factors_check_kernel(const float *a0, int pitch, int row0, int nrows, int nco
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) differ += __shfl_down(differ, off, 64);
   if ((threadIdx.x & 63) == 0 && differ) atomicAdd(&bad[n], differ);
+}
+
+// div2_shared against the compiler's IEEE division: thread i forms two numerators and a
+// denominator from a counter-based hash (every exponent, denormals, zeros, infinities and NaN
+// among the numerators; denominators 0.5 .. 2^100 -- the range the launcher admits: below it the
+// hardware scales numerator AND denominator of a tiny numerator whose quotient is not tiny, which
+// a shared unscaled reciprocal cannot follow -- half of them of the form nu^2 + x^2 near 1)
+// and counts the quotients whose bits differ (any NaN equals any NaN).
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__global__ void __launch_bounds__(256)
+division_selftest_kernel(unsigned long long count, uint32_t seed, unsigned long long *differ, float *first_bad)
+{
+  unsigned long long bad = 0;
+  for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < count;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    const uint32_t h1 = mix32((uint32_t)i * 3u + seed), h2 = mix32((uint32_t)i * 3u + 1u + seed),
+                   h3 = mix32((uint32_t)i * 3u + 2u + seed) ^ (uint32_t)(i >> 32);
+    const float n1 = __uint_as_float(h1), n2 = __uint_as_float(h2);
+    float d;
+    if (h3 & 1u) {
+      const float x = __uint_as_float(0x30000000u + (h3 >> 1) % 0x10000000u);        // 2^-31 .. 2^1
+      d = 1.0010002f + x * x;
+    } else {
+      d = __uint_as_float(((126u + (h3 >> 8) % 101u) << 23) | ((h3 >> 1) & 0x7fffffu)); // 0.5 .. 2^100
+    }
+    float q1, q2;
+    div2_shared(n1, n2, d, q1, q2);
+    const float r1 = n1 / d, r2 = n2 / d;
+    const bool ok1 = __float_as_uint(q1) == __float_as_uint(r1) || (q1 != q1 && r1 != r1);
+    const bool ok2 = __float_as_uint(q2) == __float_as_uint(r2) || (q2 != q2 && r2 != r2);
+    if (!(ok1 && ok2)) {
+      if (bad == 0 && atomicAdd(differ, 0ull) == 0) { first_bad[0] = ok1 ? n2 : n1; first_bad[1] = d; first_bad[2] = ok1 ? q2 : q1; first_bad[3] = ok1 ? r2 : r1; }
+      bad++;
+    }
+  }
+  if (bad) atomicAdd(differ, bad);
 }
 
 // ---------------------------------------------------------------------------
@@ -1199,6 +1396,256 @@ multi_step_kernel(const MultiArgs<S> p)
       a0h[0][k] = a0r[k];
       hA[1][k] = hA[0][k]; hB[1][k] = hB[0][k]; hA[0][k] = upA0[k]; hB[0][k] = upB0[k];
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The general S-steps-per-launch kernel with everything the double step has learnt: four
+// columns per lane, H halo lanes per side (H*4 >= 2S columns), the launch schedule of
+// fused2_step_kernel (whole column strips first, the rest cut into chunks of rows, neighbouring
+// strips on one XCD), non-temporal stores, the two-columns-wide point update with the shared
+// division (DIV2), and optionally (PF) the loads of stage 0's next row issued one pass of the
+// row loop ahead, so that a wave covers its own memory latency -- which matters at S = 3, where
+// registers allow two waves per SIMD only.  Same stages and hand-offs as multi_step_kernel,
+// same bits.
+// ---------------------------------------------------------------------------
+template <int S>
+struct PipeArgs {
+  static constexpr int Q = 2 * S;
+  const float *a0, *a_c, *b_c, *a_h, *b_h;
+  const float *pers_a[Q - 1], *pers_b[Q - 1];
+  float *a_o, *b_o, *a_ho, *b_ho;
+  float E_dc, E_omega, B, dt, dPhi, PhiYmin, nu, nu2, nu_tilde, bdt;
+  float c[2 * Q];
+  int N, pitch, m_offset, jj0;
+  int jf[Q], jl[Q];
+  int n_phase, wg_begin[4], g0[3], ng[3], len[3];      // as in Fused2Args
+};
+
+// RING: the stage outputs wait in LDS instead of registers.  A row a stage forms in pass r of
+// the row loop is used at once (as the next stage's row n+1) and again two passes later (as that
+// stage's row n-1 and as the centre row of the stage after it); in between it is only kept.
+// Each wave owns a ring of two slots per stage and array in LDS -- 64 lanes x 16 bytes per slot,
+// written and read with 16-byte LDS accesses, no barrier since no other wave ever sees it --
+// and a pass reads the slot it is about to overwrite.  That takes 16 (2S-1) registers per lane
+// out of the kernel (80 at S = 3, where they do not fit otherwise) and the moves that slide
+// the histories with them; it costs 4 (2S-1) KB of LDS per wave.
+template <int S, int MINW, int H, bool NTS, bool DIV2, bool PF, bool RING = false>
+__global__ void __launch_bounds__(256, MINW)
+pipe_step_kernel(const PipeArgs<S> p)
+{
+  constexpr int V = 4, Q = 2 * S, INNER = 64 - 2 * H;
+  static_assert(H * V >= Q, "halo lanes must cover one column per stage");
+  const int lane = threadIdx.x & 63;
+  int id = blockIdx.x, ph = 0;
+  if (p.n_phase > 1 && id >= p.wg_begin[1]) ph = 1;
+  if (p.n_phase > 2 && id >= p.wg_begin[2]) ph = 2;
+  id -= p.wg_begin[ph];
+  const int ng = p.ng[ph];
+  const int chunk = id / ng;
+  int bx = id - chunk * ng;
+  const int n0 = chunk * p.len[ph];
+  if (n0 >= p.N) return;                                        // padding of the phase
+  const int per_xcd = ng >> 3;
+  if (bx < (per_xcd << 3)) bx = (bx & 7) * per_xcd + (bx >> 3);
+  bx += p.g0[ph];
+  const int wave = (bx * blockDim.x + threadIdx.x) >> 6;
+  const int jj   = p.jj0 + (wave * INNER + lane - H) * V;       // first own column (may be < 0)
+  int j_hi = p.jl[0];
+#pragma unroll
+  for (int q = 1; q < Q; q++) j_hi = p.jl[q] > j_hi ? p.jl[q] : j_hi;
+  if (p.jj0 + wave * INNER * V > j_hi) return;                  // whole wave past the end
+  const bool interior = lane >= H && lane < 64 - H;
+  const int jcl = jj < 0 ? 0 : (jj > p.pitch - V ? p.pitch - V : jj);
+  const unsigned j = (unsigned)jcl;
+
+  const int n1 = n0 + p.len[ph] < p.N ? n0 + p.len[ph] : p.N;
+  const int a_lo  = n0 > Q - 1 ? n0 - (Q - 1) : 0;              // first row of stage 0
+  const int r_end = n1 + Q - 2;                                 // last stage forms row n1-1 then
+
+  float bphi[V];
+  unsigned ok = 0;          // bit q*V+k: stage q produces column k (stages 0..Q-2)
+  unsigned wr = 0;          // bit k: stage Q-2 stores column k; bit V+k: stage Q-1 stores it
+  unsigned need = 0;        // bit q: this lane must fetch never-written cells for stage q
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    const int c = jj + k;
+    bphi[k] = p.B * (p.PhiYmin + p.dPhi * (float)(p.m_offset + c - 1));
+    const bool in_row = c >= 0 && c < p.pitch;
+#pragma unroll
+    for (int q = 0; q < Q - 1; q++) {
+      const bool okq = c >= p.jf[q] && c <= p.jl[q];
+      if (okq) ok |= 1u << (q * V + k);
+      if (!okq && in_row && c >= p.jf[q + 1] - 1 && c <= p.jl[q + 1] + 1) need |= 1u << q;
+    }
+    if (interior && c >= p.jf[Q - 2] && c <= p.jl[Q - 2]) wr |= 1u << k;
+    if (interior && c >= p.jf[Q - 1] && c <= p.jl[Q - 1]) wr |= 1u << (V + k);
+  }
+  if (jj != jcl) need = 0;
+  float sc[2 * Q];
+#pragma unroll
+  for (int q = 0; q < 2 * Q; q++) sc[q] = p.E_dc + p.E_omega * p.c[q];
+
+  const size_t P = (size_t)p.pitch;
+  auto load4 = [&](const float *base, size_t row, float (&v)[V]) {
+    const float4 x = *reinterpret_cast<const float4 *>(base + row + j);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  };
+  auto store4 = [&](float *base, size_t row, const float (&v)[V]) {
+    float4 *at = reinterpret_cast<float4 *>(base + row + j);
+    if constexpr (NTS) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const f4 q = {v[0], v[1], v[2], v[3]};
+      __builtin_nontemporal_store(q, reinterpret_cast<f4 *>(at));
+    } else {
+      *at = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  constexpr unsigned ALL = (1u << V) - 1u;
+  auto diffs = [&](const float (&own)[V], float (&d)[V]) {
+    float e[V + 2];
+    widen(own, e);
+#pragma unroll
+    for (int k = 0; k < V; k++) d[k] = e[k + 2] - e[k];
+  };
+
+  // histories: index 0 = one pass ago, 1 = two passes ago
+  float hA[2][V] = {}, hB[2][V] = {};               // input half-step lattice rows r, r-1
+  constexpr int QH = RING ? 1 : Q - 1;
+  float oA[QH][2][V] = {}, oB[QH][2][V] = {};       // stage outputs (not RING)
+  float a0h[Q - 1][V] = {};                         // dt * a0, rows r-1 .. r-(Q-1)
+  // RING: slot (parity of the pass, stage, array) of this wave, one float4 per lane
+  constexpr int RING_SLOTS = RING ? 4 * (Q - 1) : 1;
+  __shared__ float4 ring_mem[RING ? 4 * RING_SLOTS * 64 : 1];
+  float4 *ring = ring_mem + ((threadIdx.x >> 6) * RING_SLOTS) * 64 + lane;
+  if constexpr (RING) {
+#pragma unroll
+    for (int i = 0; i < RING_SLOTS; i++) ring[i * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  auto ring_put = [&](int par, int q, int arr, const float (&v)[V]) {
+    ring[((par * (Q - 1) + q) * 2 + arr) * 64] = make_float4(v[0], v[1], v[2], v[3]);
+  };
+  auto ring_get = [&](int par, int q, int arr, float (&v)[V]) {
+    const float4 x = ring[((par * (Q - 1) + q) * 2 + arr) * 64];
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  };
+
+  if (a_lo >= 1) { load4(p.a_h, (size_t)(a_lo - 1) * P, hA[1]); load4(p.b_h, (size_t)(a_lo - 1) * P, hB[1]); }
+  load4(p.a_h, (size_t)a_lo * P, hA[0]); load4(p.b_h, (size_t)a_lo * P, hB[0]);
+
+  struct RowIn { float a0[V], ac[V], bc[V], upA[V], upB[V]; };
+  auto load_row = [&](int r, RowIn &in) {
+    const size_t row = (size_t)r * P;
+    load4(p.a0, row, in.a0); load4(p.a_c, row, in.ac); load4(p.b_c, row, in.bc);
+    load4(p.a_h, row + P, in.upA); load4(p.b_h, row + P, in.upB);
+  };
+  RowIn cur = {}, nxt = {};
+  if constexpr (PF) { if (a_lo < p.N) load_row(a_lo, cur); }
+
+  for (int r = a_lo; r <= r_end; r++) {
+    float nA[Q][V] = {}, nB[Q][V] = {};             // this pass's stage outputs
+    const int par = (r - a_lo) & 1;
+    // RING: the rows the stages left two passes ago (stage q-1's for stage q's row n-1, stage
+    // q-2's for its centre), fetched just before the first stage that needs them
+    float oldA[Q][V] = {}, oldB[Q][V] = {};
+    if constexpr (PF) {
+      if (r + 1 < p.N && r + 1 <= r_end) load_row(r + 1, nxt);
+    } else {
+      if (r < p.N) load_row(r, cur);
+    }
+    float a0r[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) a0r[k] = p.dt * cur.a0[k];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const int n = r - q;
+      const int lo_q = n0 > Q - 1 - q ? n0 - (Q - 1 - q) : 0;
+      if constexpr (RING) {
+        // what this stage left two passes ago is wanted by the NEXT stage (and the one after it):
+        // asked for a stage ahead, so that the LDS latency passes behind this stage's arithmetic
+        if (q <= Q - 2) { ring_get(par, q, 0, oldA[q]); ring_get(par, q, 1, oldB[q]); }
+      }
+      if (n >= lo_q && n < p.N) {
+        float ea[V + 2], eb[V + 2], la[V], lb[V];
+        // stencil: row n+1 (this pass) with its m+-1 neighbours, row n-1 as differences
+        if (q == 0) { widen(cur.upA, ea); widen(cur.upB, eb); diffs(hA[1], la); diffs(hB[1], lb); }
+        else if constexpr (RING) { widen(nA[q - 1], ea); widen(nB[q - 1], eb); diffs(oldA[q >= 1 ? q - 1 : 0], la); diffs(oldB[q >= 1 ? q - 1 : 0], lb); }
+        else        { widen(nA[q - 1], ea); widen(nB[q - 1], eb); diffs(oA[q >= 1 ? q - 1 : 0][1], la); diffs(oB[q >= 1 ? q - 1 : 0][1], lb); }
+        if (n < 2) {                               // the same for the whole wave; rows 0 and 1 only
+          asm volatile("" ::);
+#pragma unroll
+          for (int k = 0; k < V; k++) { lb[k] = 0.0f; la[k] = n == 0 ? 0.0f : 2.0f * la[k]; }
+        }
+        const float fn = (float)n;
+#pragma unroll
+        for (int k = 0; k < V; k += 2) {
+          slb_f2 ca, cb;
+          if (q == 0)      { ca = slb_f2{cur.ac[k], cur.ac[k + 1]}; cb = slb_f2{cur.bc[k], cur.bc[k + 1]}; }
+          else if (q == 1) { ca = slb_f2{hA[1][k], hA[1][k + 1]};   cb = slb_f2{hB[1][k], hB[1][k + 1]}; }
+          else if constexpr (RING) {
+            ca = slb_f2{oldA[q >= 2 ? q - 2 : 0][k], oldA[q >= 2 ? q - 2 : 0][k + 1]};
+            cb = slb_f2{oldB[q >= 2 ? q - 2 : 0][k], oldB[q >= 2 ? q - 2 : 0][k + 1]};
+          } else {
+            ca = slb_f2{oA[q >= 2 && !RING ? q - 2 : 0][1][k], oA[q >= 2 && !RING ? q - 2 : 0][1][k + 1]};
+            cb = slb_f2{oB[q >= 2 && !RING ? q - 2 : 0][1][k], oB[q >= 2 && !RING ? q - 2 : 0][1][k + 1]};
+          }
+          const slb_f2 a0v = q == 0 ? slb_f2{a0r[k], a0r[k + 1]} : slb_f2{a0h[q >= 1 ? q - 1 : 0][k], a0h[q >= 1 ? q - 1 : 0][k + 1]};
+          const slb_f2 bp = {bphi[k], bphi[k + 1]};
+          const slb_f2 mu_a = (sc[2 * q] + bp) * p.dt / 2.0f, mu_b = (sc[2 * q + 1] + bp) * p.dt / 2.0f;
+          slb_f2 qa, qb;
+          point_update_pair<DIV2>(p, fn, mu_a, mu_b, a0v, ca, cb, slb_f2{ea[k + 2], ea[k + 3]}, slb_f2{ea[k], ea[k + 1]},
+                                  slb_f2{eb[k + 2], eb[k + 3]}, slb_f2{eb[k], eb[k + 1]},
+                                  slb_f2{la[k], la[k + 1]}, slb_f2{lb[k], lb[k + 1]}, qa, qb);
+          nA[q][k] = qa.x; nA[q][k + 1] = qa.y; nB[q][k] = qb.x; nB[q][k + 1] = qb.y;
+        }
+        const size_t row = (size_t)n * P;
+        if (q >= Q - 2 && n >= n0 && n < n1) {
+          float *da = q == Q - 2 ? p.a_o : p.a_ho, *db = q == Q - 2 ? p.b_o : p.b_ho;
+          const unsigned w = q == Q - 2 ? (wr & ALL) : (wr >> V);
+          if (w == ALL) {
+            store4(da, row, nA[q]);
+            if (n > 0) store4(db, row, nB[q]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+              if (w & (1u << k)) {
+                da[row + j + k] = nA[q][k];
+                if (n > 0) db[row + j + k] = nB[q][k];
+              }
+            }
+          }
+        }
+        if (q < Q - 1) {
+          if (need & (1u << q)) {
+            float xa[V], xb[V];
+            load4(p.pers_a[q], row, xa); load4(p.pers_b[q], row, xb);
+#pragma unroll
+            for (int k = 0; k < V; k++)
+              if (!(ok & (1u << (q * V + k)))) { nA[q][k] = xa[k]; nB[q][k] = xb[k]; }
+          }
+          if constexpr (RING) { ring_put(par, q, 0, nA[q]); ring_put(par, q, 1, nB[q]); }
+        }
+      } else if (q < Q - 1 && n == p.N) {
+        // row N is never written: the stage's "output" there is what its buffer holds
+        load4(p.pers_a[q], (size_t)n * P, nA[q]); load4(p.pers_b[q], (size_t)n * P, nB[q]);
+      }
+    }
+    // ---- slide every history one row up ----
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+      if constexpr (!RING) {
+#pragma unroll
+        for (int q = 0; q < Q - 1; q++) {
+          oA[q][1][k] = oA[q][0][k]; oB[q][1][k] = oB[q][0][k];
+          oA[q][0][k] = nA[q][k];    oB[q][0][k] = nB[q][k];
+        }
+      }
+#pragma unroll
+      for (int q = Q - 2; q >= 1; q--) a0h[q][k] = a0h[q - 1][k];
+      a0h[0][k] = a0r[k];
+      hA[1][k] = hA[0][k]; hB[1][k] = hB[0][k]; hA[0][k] = cur.upA[k]; hB[0][k] = cur.upB[k];
+    }
+    if constexpr (PF) cur = nxt;
   }
 }
 
@@ -1808,7 +2255,7 @@ int resident_workgroups(K kernel, int block)
 // and only the groups left over are cut into chunks (`tail_chunk` rows, or shorter ones when
 // the lattice has few rounds); narrower lattices are cut into chunks of `tail_chunk` rows
 // throughout.
-template <int MINW, bool DIAG = false, bool ROWS = false, int H = 2, bool NTS = true, bool NTL = false, int A0F = 0>
+template <int MINW, bool DIAG = false, bool ROWS = false, int H = 2, bool NTS = true, bool NTL = false, int A0F = 0, int OPT = 0>
 int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
 {
   int lo = args.jf[0], hi = args.jl[0];
@@ -1820,7 +2267,7 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
   const int groups = (waves + wpb - 1) / wpb;
   auto chunks_of = [&](int len) { return (args.N + len - 1) / len; };
   // (tuning variant 39: as if the occupancy query had failed -- every strip is cut into chunks)
-  const int slots = n_chunk > 0 || g_variant == 39 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL, A0F>, block);
+  const int slots = n_chunk > 0 || g_variant == 39 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL, A0F, OPT>, block);
   // (measured on MI355X with two halo lanes and non-temporal stores: whole groups first wins
   // from one round of workgroups up -- 2.02 against 2.11 ms at 128 rows x 2^21 columns, 2.06
   // against 2.15 at 256 x 2^20, 0.53 against 0.57 at 64 x 2^20, 1.02-1.04 against 1.03-1.08 at
@@ -1851,8 +2298,62 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
     args.wg_begin[2] = args.wg_begin[1] + (groups - whole) * chunks_of(tail_chunk);
   }
   for (int k = args.n_phase; k < 3; k++) { args.g0[k] = 0; args.ng[k] = 1; args.len[k] = args.N; args.wg_begin[k + 1] = args.wg_begin[k]; }
-  hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL, A0F>), dim3(args.wg_begin[args.n_phase]), dim3(block), 0,
+  hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL, A0F, OPT>), dim3(args.wg_begin[args.n_phase]), dim3(block), 0,
                      launch_stream(), args);
+  return (int)hipGetLastError();
+}
+
+// The scheduled general kernel: whole strip groups first, the rest in chunks (see launch_fused2).
+template <int S, int MINW, int H, bool NTS, bool DIV2, bool PF, bool RING = false>
+int launch_pipe_sched(const slb_multi_geom *g, const float *a0, const float *const *in, const float *const *pers_a,
+                      const float *const *pers_b, float *const *out, const float *cosines, int block, int n_chunk)
+{
+  constexpr int Q = 2 * S;
+  PipeArgs<S> s;
+  s.a0 = a0; s.a_c = in[0]; s.b_c = in[1]; s.a_h = in[2]; s.b_h = in[3];
+  for (int q = 0; q < Q - 1; q++) { s.pers_a[q] = pers_a[q]; s.pers_b[q] = pers_b[q]; }
+  s.a_o = out[0]; s.b_o = out[1]; s.a_ho = out[2]; s.b_ho = out[3];
+  s.E_dc = g_phys.E_dc; s.E_omega = g_phys.E_omega; s.B = g_phys.B; s.dt = g_phys.dt;
+  s.dPhi = g_phys.dPhi; s.PhiYmin = g_phys.PhiYmin; s.nu = g_phys.nu; s.nu2 = g_phys.nu2;
+  s.nu_tilde = g_phys.nu_tilde; s.bdt = g_phys.bdt;
+  for (int q = 0; q < 2 * Q; q++) s.c[q] = cosines[q];
+  s.N = g_phys.N; s.pitch = g->pitch; s.m_offset = g->m_offset;
+  int lo = g->j_first[0], hi = g->j_last[0];
+  for (int q = 0; q < Q; q++) {
+    s.jf[q] = g->j_first[q]; s.jl[q] = g->j_last[q];
+    lo = s.jf[q] < lo ? s.jf[q] : lo; hi = s.jl[q] > hi ? s.jl[q] : hi;
+  }
+  s.jj0 = lo / 32 * 32;
+  const int per_wave = (64 - 2 * H) * 4;
+  const int waves = (hi + 1 - s.jj0 + per_wave - 1) / per_wave;
+  const int wpb = block / 64;
+  const int groups = (waves + wpb - 1) / wpb;
+  auto chunks_of = [&](int len) { return (s.N + len - 1) / len; };
+  const int slots = n_chunk > 0 ? 0 : resident_workgroups(pipe_step_kernel<S, MINW, H, NTS, DIV2, PF, RING>, block);
+  const int whole = slots > 0 && groups >= slots ? groups / slots * slots : 0;
+  int tail_chunk = s.N >= 128 ? (7 * s.N + 15) / 16 : 32;
+  if (whole > 0 && whole < groups && groups < 4 * slots) {
+    int c = (slots + (groups - whole) - 1) / (groups - whole);
+    c = c < 3 ? 3 : c;
+    tail_chunk = (s.N + c - 1) / c;
+    if (tail_chunk < 4 * Q) tail_chunk = s.N < 4 * Q ? s.N : 4 * Q;     // a chunk re-forms Q-1 rows above itself
+  }
+  if (n_chunk <= 0 && whole == 0) n_chunk = auto_chunk(s.N, hi - lo + 1, per_wave, block, tail_chunk, 2 * (slots > 0 ? slots : 768));
+  if (n_chunk > 0) {
+    if (n_chunk > s.N) n_chunk = s.N;
+    s.n_phase = 1;
+    s.g0[0] = 0; s.ng[0] = groups; s.len[0] = n_chunk;
+    s.wg_begin[0] = 0; s.wg_begin[1] = groups * chunks_of(n_chunk);
+  } else {
+    if (tail_chunk > s.N) tail_chunk = s.N;
+    s.n_phase = whole < groups ? 2 : 1;
+    s.g0[0] = 0; s.ng[0] = whole; s.len[0] = s.N;
+    s.wg_begin[0] = 0; s.wg_begin[1] = (whole + 7) / 8 * 8;
+    s.g0[1] = whole; s.ng[1] = groups - whole; s.len[1] = tail_chunk;
+    s.wg_begin[2] = s.wg_begin[1] + (groups - whole) * chunks_of(tail_chunk);
+  }
+  for (int k = s.n_phase; k < 3; k++) { s.g0[k] = 0; s.ng[k] = 1; s.len[k] = s.N; s.wg_begin[k + 1] = s.wg_begin[k]; }
+  hipLaunchKernelGGL((pipe_step_kernel<S, MINW, H, NTS, DIV2, PF, RING>), dim3(s.wg_begin[s.n_phase]), dim3(block), 0, launch_stream(), s);
   return (int)hipGetLastError();
 }
 
@@ -2088,6 +2589,13 @@ int slb_step_fused2_factored(const slb_step2_geom *g, const float *a0, const dou
                           a_next_hs, b_next_hs, a_out, b_out, a_out_hs, b_out_hs, cosines, rows_first, rows_second);
 }
 
+int slb_selftest_division(unsigned long long count, unsigned seed, unsigned long long *differ, float *first_bad)
+{
+  if (!differ || !first_bad) return -1;
+  hipLaunchKernelGGL(division_selftest_kernel, dim3(4096), dim3(256), 0, launch_stream(), count, (uint32_t)seed, differ, first_bad);
+  return (int)hipGetLastError();
+}
+
 int slb_a0_factors_check(const float *a0, int pitch, int row_first, int nrows, int ncols,
                          const double *a0_row, const double *a0_col, int *bad)
 {
@@ -2203,6 +2711,19 @@ static int step_fused2_impl(const slb_step2_geom *g, const float *a0, const doub
     return rows_first ? launch_fused2<3, false, true, 2, true, false, 1>(s, block, n_chunk, tail_chunk)
                       : launch_fused2<3, false, false, 2, true, false, 1>(s, block, n_chunk, tail_chunk);
   }
+  // tuning variants 60 / 61: the point update with fewer instructions (61: and the shared division)
+  if (g_variant == 60)
+    return rows_first ? launch_fused2<3, false, true, 2, true, false, 0, 1>(s, block, n_chunk, tail_chunk)
+                      : launch_fused2<3, false, false, 2, true, false, 0, 1>(s, block, n_chunk, tail_chunk);
+  if (g_variant == 61)
+    return rows_first ? launch_fused2<3, false, true, 2, true, false, 0, 3>(s, block, n_chunk, tail_chunk)
+                      : launch_fused2<3, false, false, 2, true, false, 0, 3>(s, block, n_chunk, tail_chunk);
+  if (g_variant == 62)
+    return rows_first ? launch_fused2<3, false, true, 2, true, false, 0, 5>(s, block, n_chunk, tail_chunk)
+                      : launch_fused2<3, false, false, 2, true, false, 0, 5>(s, block, n_chunk, tail_chunk);
+  if (g_variant == 63)
+    return rows_first ? launch_fused2<3, false, true, 2, true, false, 0, 7>(s, block, n_chunk, tail_chunk)
+                      : launch_fused2<3, false, false, 2, true, false, 0, 7>(s, block, n_chunk, tail_chunk);
   if (rows_first) return launch_fused2<3, false, true>(s, block, n_chunk, tail_chunk);
   // default: two halo lanes per side (the 60 interior lanes' stores start on 64-byte boundaries),
   // non-temporal stores, registers for 3 waves per SIMD.  The rest are tuning variants.
@@ -2261,6 +2782,44 @@ int slb_step_multi(const slb_multi_geom *g, const float *a0, const float *const 
       case 40: return launch_multi<4, 2, 2>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
       case 41: return launch_multi<4, 2, 3>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
       case 42: return launch_multi<4, 2, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
+      default: break;
+    }
+  }
+  // tuning variants 70..75: the scheduled kernel (pipe_step_kernel), four columns per lane, two halo
+  // lanes per side, non-temporal stores, packed point update with the shared division:
+  //   70 / 71: S as given, register budget of 3 / 2 waves per SIMD;  72 / 73: the same with stage 0's
+  //   loads a pass ahead;  74 / 75: 71 / 73 with the compiler's own division
+  if (v >= 70 && v <= 75 && (g->steps == 2 || g->steps == 3)) {
+    const int nc = g_n_chunk;
+    switch (g->steps * 100 + v) {
+      case 270: return launch_pipe_sched<2, 3, 2, true, true, false>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 271: return launch_pipe_sched<2, 2, 2, true, true, false>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 272: return launch_pipe_sched<2, 3, 2, true, true, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 273: return launch_pipe_sched<2, 2, 2, true, true, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 370: return launch_pipe_sched<3, 3, 2, true, true, false>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 371: return launch_pipe_sched<3, 2, 2, true, true, false>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 372: return launch_pipe_sched<3, 3, 2, true, true, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 373: return launch_pipe_sched<3, 2, 2, true, true, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 374: return launch_pipe_sched<3, 2, 2, true, false, false>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 375: return launch_pipe_sched<3, 2, 2, true, false, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      default: break;
+    }
+  }
+  // tuning variants 80..85: the same kernel with the stage outputs kept in an LDS ring per wave:
+  //   80 / 81: register budget of 3 / 2 waves per SIMD;  82 / 83: the same with stage 0's loads a
+  //   pass ahead;  84: budget of 4 waves per SIMD (S = 2)
+  if (v >= 80 && v <= 85 && (g->steps == 2 || g->steps == 3)) {
+    const int nc = g_n_chunk;
+    if (block != 256) { fprintf(stderr, "slb_step_multi: the LDS ring is laid out for 256 threads\n"); return -1; }
+    switch (g->steps * 100 + v) {
+      case 280: return launch_pipe_sched<2, 3, 2, true, true, false, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 281: return launch_pipe_sched<2, 2, 2, true, true, false, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 282: return launch_pipe_sched<2, 3, 2, true, true, true, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 284: return launch_pipe_sched<2, 4, 2, true, true, false, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 380: return launch_pipe_sched<3, 3, 2, true, true, false, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 381: return launch_pipe_sched<3, 2, 2, true, true, false, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 382: return launch_pipe_sched<3, 3, 2, true, true, true, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      case 383: return launch_pipe_sched<3, 2, 2, true, true, true, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
       default: break;
     }
   }

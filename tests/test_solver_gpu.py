@@ -334,7 +334,7 @@ def test_double_step_bit_exact(slb, oracle, N, M, B, omega, pairs, n_chunk):
     L = slb.lib()
     try:
         sol.tiptoe()
-        for variant in (0, 20, 21, 23, 24, 25, 26, 27, 29, 30, 34, 38, 39, 50, 51):
+        for variant in (0, 20, 21, 23, 24, 25, 26, 27, 29, 30, 34, 38, 39, 50, 51, 60, 61, 62, 63):
             L.slb_set_tuning(variant, n_chunk, 0)
             for _ in range(pairs):
                 sol.double_step()
@@ -352,12 +352,14 @@ def test_double_step_bit_exact(slb, oracle, N, M, B, omega, pairs, n_chunk):
         orc.close()
 
 
-@pytest.mark.parametrize("S,variant", [(1, 0), (2, 0), (3, 0), (4, 0), (2, 34), (3, 32), (3, 33), (4, 32), (2, 35), (2, 37), (3, 36), (4, 35), (4, 36)])
+@pytest.mark.parametrize("S,variant", [(1, 0), (2, 0), (3, 0), (4, 0), (2, 34), (3, 32), (3, 33), (4, 32), (2, 35), (2, 37), (3, 36), (4, 35), (4, 36),
+                                       (2, 70), (2, 73), (3, 71), (3, 72), (3, 73), (3, 74), (3, 75),
+                                       (2, 80), (2, 82), (2, 84), (3, 80), (3, 81), (3, 83)])
 @pytest.mark.parametrize("N,M,B,omega,n_chunk", [
     (1, 5, 0.5, 3.0, 0), (2, 61, 0.05, 100.0, 0), (5, 61, 0.05, 100.0, 2), (7, 300, 0.4, 10.0, 3),
     (32, 4096, 1.0, 1.0, 0), (33, 1000, 0.5, 30.0, 5), (16, 239, 0.3, 10.0, 0), (16, 240, 0.3, 10.0, 8),
     (16, 241, 0.3, 10.0, 1), (64, 20001, 0.2, 10.0, 16), (16, 115, 0.3, 10.0, 0), (16, 116, 0.3, 10.0, 0),
-    (16, 117, 0.3, 10.0, 0),
+    (16, 117, 0.3, 10.0, 0), (70, 200001, 0.02, 30.0, 0),
 ])
 def test_multi_step_bit_exact(slb, oracle, S, variant, N, M, B, omega, n_chunk):
     """S loop iterations per launch (general kernel, four columns per lane or -- variants
@@ -435,6 +437,21 @@ def test_double_step_hands_out_the_rows_av_reads(slb, oracle, N, M, B, omega):
     finally:
         sol.close()
         orc.close()
+
+
+@pytest.mark.parametrize("seed", [1, 20251111])
+def test_shared_reciprocal_division_is_the_ieee_division(slb, seed):
+    """div2_shared (one refined reciprocal for the two quotients of a point, hardware scaling of
+    the numerators only) against the compiler's IEEE division on the GPU: 2^32 pseudo-random
+    triples per seed -- numerators over every bit pattern (denormals, zeros, infinities, NaN),
+    denominators from 0.5 to 2^100 and of the form nu^2 + x^2 -- not one bit may differ."""
+    import torch
+    L = slb.lib()
+    differ = torch.zeros(1, dtype=torch.int64, device="cuda")
+    first = torch.zeros(4, dtype=torch.float32, device="cuda")
+    assert L.slb_selftest_division(1 << 32, seed, differ.data_ptr(), first.data_ptr()) == 0
+    torch.cuda.synchronize()
+    assert int(differ.item()) == 0, f"{int(differ.item())} quotients differ; first: n, d, got, expected = {first.cpu().numpy()}"
 
 
 @pytest.mark.parametrize("N,M,mu", [(32, 4096, 5.0), (128, 300001, 5.0), (64, 70001, 0.7), (24, 5003, 31.0)])
