@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/slb_abi.h"
 
@@ -42,6 +43,7 @@ thread_local int         t_stream_depth = 0;
 inline hipStream_t launch_stream() { return t_stream_depth > 0 ? t_stream[t_stream_depth - 1] : g_stream; }
 int         g_av_mode = SLB_AV_EXACT;
 int         g_variant = 0, g_n_chunk = 0, g_block = 0;
+unsigned long long *g_stamps = nullptr;   // timing builds: slb_debug_set_stamps()
 double     *g_ws = nullptr;          // reduction workspace, allocated once
 int         g_ws_device = -1;
 constexpr int kMaxAvBlocks = 1024;
@@ -1420,6 +1422,7 @@ struct PipeArgs {
   int N, pitch, m_offset, jj0;
   int jf[Q], jl[Q];
   int n_phase, wg_begin[4], g0[3], ng[3], len[3];      // as in Fused2Args
+  int edge_last;                                       // > 0: phase 0 holds two strip groups, the first and this one
 };
 
 // RING: the stage outputs wait in LDS instead of registers.  A row a stage forms in pass r of
@@ -1646,6 +1649,339 @@ pipe_step_kernel(const PipeArgs<S> p)
       hA[1][k] = hA[0][k]; hB[1][k] = hB[0][k]; hA[0][k] = cur.upA[k]; hB[0][k] = cur.upB[k];
     }
     if constexpr (PF) cur = nxt;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// ring_step_kernel: pipe_step_kernel's RING form with the row loop written twice.
+//
+// What held the ring kernel back at three steps per launch was not its arithmetic but that a
+// wave stood still for the whole memory latency at the top of every pass: the loop body held
+// loads under conditions (never-written cells for the lanes at the lattice's edges, row N at the
+// end of a strip, single-column stores at a ragged right edge), so every wait in it had to be a
+// wait for ALL outstanding accesses -- the previous pass's stores included -- and loads issued a
+// pass ahead could not stay in flight.  Here a wave first asks whether any of its lanes ever
+// needs those cases (only the waves at the two ends of the lattice do); if none does, the passes in
+// which every stage is active, stores, and is past rows 0 and 1 run a body without a single
+// branch: the five input rows of pass r+1 are requested at the top of pass r (the row loop is
+// unrolled by two, so the two register sets just alternate and the ring slots have fixed
+// addresses), stores of halo lanes are dropped by the buffer bounds check (their offset lies
+// beyond the row's end) instead of by a branch, and the only wait for memory is the one that lets
+// the four stores of the pass before stay outstanding.  The first and last passes of a strip, and
+// all passes of the edge waves, run the general body (the RING body of pipe_step_kernel).
+// Same stages, same hand-offs, same point update: same bits.
+//
+// ROWS: as in the double step, rows 0 and 1 of a and row 1 of b of every new main lattice
+// (stages 0, 2, .., 2S-2) also go to small side buffers for av(); only general passes form them.
+// ---------------------------------------------------------------------------
+template <int S>
+struct RingArgs {
+  PipeArgs<S> p;
+  float *rows[S];                                      // ROWS: [3][pitch] each
+  unsigned long long *stamps;                          // timing builds (X == 4): per wave start, end, HW_ID, XCC_ID
+};
+
+typedef unsigned int slb_u4 __attribute__((vector_size(16)));
+typedef float slb_f4 __attribute__((vector_size(16)));
+
+template <int S, int MINW, bool ROWS = false, bool DIV2 = true, int X = 0>
+__global__ void __launch_bounds__(256, MINW)
+ring_step_kernel(const RingArgs<S> ra)
+{
+  const PipeArgs<S> &p = ra.p;
+  constexpr int V = 4, Q = 2 * S, H = 2, INNER = 64 - 2 * H;
+  static_assert(H * V >= Q, "halo lanes must cover one column per stage");
+  const int lane = threadIdx.x & 63;
+  int id = blockIdx.x, ph = 0;
+  if (p.n_phase > 1 && id >= p.wg_begin[1]) ph = 1;
+  if (p.n_phase > 2 && id >= p.wg_begin[2]) ph = 2;
+  id -= p.wg_begin[ph];
+  const int ng = p.ng[ph];
+  const int chunk = id / ng;
+  int bx = id - chunk * ng;
+  const int n0 = chunk * p.len[ph];
+  if (n0 >= p.N) return;                                        // padding of the phase
+  const int per_xcd = ng >> 3;
+  if (bx < (per_xcd << 3)) bx = (bx & 7) * per_xcd + (bx >> 3);
+  bx += p.g0[ph];
+  if (ph == 0 && p.edge_last > 0 && bx > 0) bx = p.edge_last;
+  const int wave = __builtin_amdgcn_readfirstlane((bx * blockDim.x + threadIdx.x) >> 6);
+  const int jj   = p.jj0 + (wave * INNER + lane - H) * V;       // first own column (may be < 0)
+  int j_hi = p.jl[0];
+#pragma unroll
+  for (int q = 1; q < Q; q++) j_hi = p.jl[q] > j_hi ? p.jl[q] : j_hi;
+  if (p.jj0 + wave * INNER * V > j_hi) return;                  // whole wave past the end
+  unsigned long long t_start = 0;
+  if constexpr (X == 4) t_start = __builtin_amdgcn_s_memrealtime();
+  if constexpr (X == 5) __builtin_amdgcn_s_sleep(0), __builtin_amdgcn_s_sleep(0);
+  if constexpr (X == 5) { for (int i = (blockIdx.x * 5 + (threadIdx.x >> 6) * 3) & 15; i > 0; i--) __builtin_amdgcn_s_sleep(16); }
+  const bool interior = lane >= H && lane < 64 - H;
+  const int jcl = jj < 0 ? 0 : (jj > p.pitch - V ? p.pitch - V : jj);
+  const unsigned j = (unsigned)jcl;
+
+  const int n1 = n0 + p.len[ph] < p.N ? n0 + p.len[ph] : p.N;
+  const int a_lo  = n0 > Q - 1 ? n0 - (Q - 1) : 0;              // first row of stage 0
+  const int r_end = n1 + Q - 2;                                 // last stage forms row n1-1 then
+
+  float bphi[V];
+  unsigned ok = 0;          // bit q*V+k: stage q produces column k (stages 0..Q-2)
+  unsigned wr = 0;          // bit k: stage Q-2 stores column k; bit V+k: stage Q-1 stores it
+  unsigned need = 0;        // bit q: this lane must fetch never-written cells for stage q
+#pragma unroll
+  for (int k = 0; k < V; k++) {
+    const int c = jj + k;
+    bphi[k] = p.B * (p.PhiYmin + p.dPhi * (float)(p.m_offset + c - 1));
+    const bool in_row = c >= 0 && c < p.pitch;
+#pragma unroll
+    for (int q = 0; q < Q - 1; q++) {
+      const bool okq = c >= p.jf[q] && c <= p.jl[q];
+      if (okq) ok |= 1u << (q * V + k);
+      if (!okq && in_row && c >= p.jf[q + 1] - 1 && c <= p.jl[q + 1] + 1) need |= 1u << q;
+    }
+    if (interior && c >= p.jf[Q - 2] && c <= p.jl[Q - 2]) wr |= 1u << k;
+    if (interior && c >= p.jf[Q - 1] && c <= p.jl[Q - 1]) wr |= 1u << (V + k);
+  }
+  if (jj != jcl) need = 0;
+  float sc[2 * Q];
+#pragma unroll
+  for (int q = 0; q < 2 * Q; q++) sc[q] = p.E_dc + p.E_omega * p.c[q];
+
+  const size_t P = (size_t)p.pitch;
+  auto load4 = [&](const float *base, size_t row, float (&v)[V]) {
+    const float4 x = *reinterpret_cast<const float4 *>(base + row + j);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  };
+  auto store4 = [&](float *base, size_t row, const float (&v)[V]) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 q = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(q, reinterpret_cast<f4 *>(base + row + j));
+  };
+  // branch-free accesses of the steady passes: a descriptor per row (base of the row, its length
+  // in bytes), the lane's byte offset in the row; an offset beyond the row's end drops a store
+  constexpr int kRsrcFlags = 0x00020000;                       // raw 32-bit data, no swizzle
+  const int row_bytes = p.pitch * 4;
+  const int off_ld = (int)(j * 4u);
+  const int off_st = (wr == 0xffu) ? off_ld : (int)0x80000000u;
+  auto bload4 = [&](const float *base, size_t row, float (&v)[V]) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(base + row), 0, row_bytes, kRsrcFlags);
+    // (the whole vector is re-typed at once: __builtin_bit_cast of a single vector element reads element 0)
+    const slb_f4 x = __builtin_bit_cast(slb_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, off_ld, 0, 0));
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+  };
+  auto bstore4 = [&](float *base, size_t row, const float (&v)[V]) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(base + row), 0, row_bytes, kRsrcFlags);
+    const slb_f4 x = {v[0], v[1], v[2], v[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(slb_u4, x), rs, off_st, 0, 2);    // 2: non-temporal
+  };
+  constexpr unsigned ALL = (1u << V) - 1u;
+  auto diffs = [&](const float (&own)[V], float (&d)[V]) {
+    float e[V + 2];
+    widen(own, e);
+#pragma unroll
+    for (int k = 0; k < V; k++) d[k] = e[k + 2] - e[k];
+  };
+
+  float hA[2][V] = {}, hB[2][V] = {};               // input half-step lattice rows r, r-1
+  float a0h[Q - 1][V] = {};                         // dt * a0, rows r-1 .. r-(Q-1)
+  // slot (parity of the pass, stage, array) of this wave's ring, one float4 per lane
+  constexpr int RING_SLOTS = 4 * (Q - 1);
+  __shared__ float4 ring_mem[4 * RING_SLOTS * 64];
+  float4 *ring = ring_mem + ((threadIdx.x >> 6) * RING_SLOTS) * 64 + lane;
+#pragma unroll
+  for (int i = 0; i < RING_SLOTS; i++) ring[i * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  auto ring_put = [&](int par, int q, int arr, const float (&v)[V]) {
+    ring[((par * (Q - 1) + q) * 2 + arr) * 64] = make_float4(v[0], v[1], v[2], v[3]);
+  };
+  auto ring_get = [&](int par, int q, int arr, float (&v)[V]) {
+    const float4 x = ring[((par * (Q - 1) + q) * 2 + arr) * 64];
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  };
+
+  if (a_lo >= 1) { load4(p.a_h, (size_t)(a_lo - 1) * P, hA[1]); load4(p.b_h, (size_t)(a_lo - 1) * P, hB[1]); }
+  load4(p.a_h, (size_t)a_lo * P, hA[0]); load4(p.b_h, (size_t)a_lo * P, hB[0]);
+
+  struct RowIn { float a0[V], ac[V], bc[V], upA[V], upB[V]; };
+  auto load_row = [&](int r, RowIn &in) {
+    const size_t row = (size_t)r * P;
+    load4(p.a0, row, in.a0); load4(p.a_c, row, in.ac); load4(p.b_c, row, in.bc);
+    load4(p.a_h, row + P, in.upA); load4(p.b_h, row + P, in.upB);
+  };
+  auto bload_row = [&](int r, RowIn &in) {
+    const size_t row = (size_t)r * P;
+    bload4(p.a0, row, in.a0); bload4(p.a_c, row, in.ac); bload4(p.b_c, row, in.bc);
+    bload4(p.a_h, row + P, in.upA); bload4(p.b_h, row + P, in.upB);
+  };
+
+  // one pass of the row loop: stage q forms row r-q.  ST: the branch-free form (every stage
+  // active and past row 1, both last stages store whole float4s or nothing, no never-written
+  // cells, PAR = r & 1 known when compiling, the rows of pass r+1 requested into `nxt`).
+  auto pass = [&](auto st_tag, auto par_tag, int r, RowIn &cur, RowIn &nxt) {
+    constexpr bool ST = decltype(st_tag)::value;
+    const int par = ST ? (int)decltype(par_tag)::value : (r & 1);
+    float nA[Q][V] = {}, nB[Q][V] = {};             // this pass's stage outputs
+    float oldA[Q][V] = {}, oldB[Q][V] = {};         // what the stages left two passes ago
+    if constexpr (ST && X != 1) bload_row(r + 1, nxt);
+    else if constexpr (ST) bload_row(r, cur);
+    else if (r < p.N) load_row(r, cur);
+    float a0r[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) a0r[k] = p.dt * cur.a0[k];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const int n = r - q;
+      const int lo_q = n0 > Q - 1 - q ? n0 - (Q - 1 - q) : 0;
+      // what this stage left two passes ago is wanted by the NEXT stage (and the one after it):
+      // asked for a stage ahead, so that the LDS latency passes behind this stage's arithmetic
+      if (q <= Q - 2) { ring_get(par, q, 0, oldA[q]); ring_get(par, q, 1, oldB[q]); }
+      if (ST || (n >= lo_q && n < p.N)) {
+        float ea[V + 2], eb[V + 2], la[V], lb[V];
+        // stencil: row n+1 (this pass) with its m+-1 neighbours, row n-1 as differences
+        if (q == 0) { widen(cur.upA, ea); widen(cur.upB, eb); diffs(hA[1], la); diffs(hB[1], lb); }
+        else        { widen(nA[q >= 1 ? q - 1 : 0], ea); widen(nB[q >= 1 ? q - 1 : 0], eb);
+                      diffs(oldA[q >= 1 ? q - 1 : 0], la); diffs(oldB[q >= 1 ? q - 1 : 0], lb); }
+        if (!ST && n < 2) {                        // the same for the whole wave; rows 0 and 1 only
+          asm volatile("" ::);
+#pragma unroll
+          for (int k = 0; k < V; k++) { lb[k] = 0.0f; la[k] = n == 0 ? 0.0f : 2.0f * la[k]; }
+        }
+        const float fn = (float)n;
+#pragma unroll
+        for (int k = 0; k < V; k += 2) {
+          slb_f2 ca, cb;
+          if (q == 0)      { ca = slb_f2{cur.ac[k], cur.ac[k + 1]}; cb = slb_f2{cur.bc[k], cur.bc[k + 1]}; }
+          else if (q == 1) { ca = slb_f2{hA[1][k], hA[1][k + 1]};   cb = slb_f2{hB[1][k], hB[1][k + 1]}; }
+          else {
+            ca = slb_f2{oldA[q >= 2 ? q - 2 : 0][k], oldA[q >= 2 ? q - 2 : 0][k + 1]};
+            cb = slb_f2{oldB[q >= 2 ? q - 2 : 0][k], oldB[q >= 2 ? q - 2 : 0][k + 1]};
+          }
+          const slb_f2 a0v = q == 0 ? slb_f2{a0r[k], a0r[k + 1]} : slb_f2{a0h[q >= 1 ? q - 1 : 0][k], a0h[q >= 1 ? q - 1 : 0][k + 1]};
+          // (the field terms are the same in every pass; formed here all the same, behind a fence the
+          // optimiser cannot see through, because carried across the loop they would cost 8 S registers)
+          slb_f2 bp = {bphi[k], bphi[k + 1]};
+          if constexpr (ST && X != 6) asm volatile("" : "+v"(bp));
+          const slb_f2 mu_a = (sc[2 * q] + bp) * p.dt / 2.0f, mu_b = (sc[2 * q + 1] + bp) * p.dt / 2.0f;
+          slb_f2 qa, qb;
+          point_update_pair<DIV2>(p, fn, mu_a, mu_b, a0v, ca, cb, slb_f2{ea[k + 2], ea[k + 3]}, slb_f2{ea[k], ea[k + 1]},
+                                  slb_f2{eb[k + 2], eb[k + 3]}, slb_f2{eb[k], eb[k + 1]},
+                                  slb_f2{la[k], la[k + 1]}, slb_f2{lb[k], lb[k + 1]}, qa, qb);
+          nA[q][k] = qa.x; nA[q][k + 1] = qa.y; nB[q][k] = qb.x; nB[q][k + 1] = qb.y;
+        }
+        const size_t row = (size_t)n * P;
+        if constexpr (ST) {
+          // (one stage at a time: left to itself the scheduler interleaves the stages of the branch-free
+          // body for parallelism it has no registers for)
+          if constexpr (X != 3) __builtin_amdgcn_sched_barrier(0);
+          if (q >= Q - 2 && X != 2) {
+            bstore4(q == Q - 2 ? p.a_o : p.a_ho, row, nA[q]);
+            bstore4(q == Q - 2 ? p.b_o : p.b_ho, row, nB[q]);
+          }
+          if (q < Q - 1) { ring_put(par, q, 0, nA[q]); ring_put(par, q, 1, nB[q]); }
+        } else {
+          if (q >= Q - 2 && n >= n0 && n < n1) {
+            float *da = q == Q - 2 ? p.a_o : p.a_ho, *db = q == Q - 2 ? p.b_o : p.b_ho;
+            const unsigned w = q == Q - 2 ? (wr & ALL) : (wr >> V);
+            if (w == ALL) {
+              store4(da, row, nA[q]);
+              if (n > 0) store4(db, row, nB[q]);
+            } else {
+#pragma unroll
+              for (int k = 0; k < V; k++) {
+                if (w & (1u << k)) {
+                  da[row + j + k] = nA[q][k];
+                  if (n > 0) db[row + j + k] = nB[q][k];
+                }
+              }
+            }
+          }
+          if constexpr (ROWS) {
+            // a main lattice's rows 0 and 1 come from the chunk that starts at row 0
+            if ((q & 1) == 0 && n <= 1 && n0 == 0 && interior) {
+              float *rows = ra.rows[q >> 1];
+#pragma unroll
+              for (int k = 0; k < V; k++) {
+                if ((q == Q - 2 ? (wr >> k) & 1u : (ok >> (q * V + k)) & 1u)) {
+                  rows[row + j + k] = nA[q][k];
+                  if (n == 1) rows[2 * P + j + k] = nB[q][k];
+                }
+              }
+            }
+          }
+          if (q < Q - 1) {
+            if (need & (1u << q)) {
+              float xa[V], xb[V];
+              load4(p.pers_a[q], row, xa); load4(p.pers_b[q], row, xb);
+#pragma unroll
+              for (int k = 0; k < V; k++)
+                if (!(ok & (1u << (q * V + k)))) { nA[q][k] = xa[k]; nB[q][k] = xb[k]; }
+            }
+            ring_put(par, q, 0, nA[q]); ring_put(par, q, 1, nB[q]);
+          }
+        }
+      } else if (q < Q - 1 && n == p.N) {
+        // row N is never written: the stage's "output" there is what its buffer holds
+        load4(p.pers_a[q], (size_t)n * P, nA[q]); load4(p.pers_b[q], (size_t)n * P, nB[q]);
+        if constexpr (ROWS) {
+          // a single harmonic: row 1 is the row no sweep writes, and av() reads it all the same
+          if ((q & 1) == 0 && n == 1 && n0 == 0 && interior) {
+            float *rows = ra.rows[q >> 1];
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+              if ((ok >> (q * V + k)) & 1u) { rows[P + j + k] = nA[q][k]; rows[2 * P + j + k] = nB[q][k]; }
+            }
+          }
+        }
+      }
+    }
+    // ---- slide the histories that live in registers one row up ----
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+#pragma unroll
+      for (int q = Q - 2; q >= 1; q--) a0h[q][k] = a0h[q - 1][k];
+      a0h[0][k] = a0r[k];
+      hA[1][k] = hA[0][k]; hB[1][k] = hB[0][k]; hA[0][k] = cur.upA[k]; hB[0][k] = cur.upB[k];
+    }
+  };
+
+  // may this wave run the branch-free passes at all?  every lane: no never-written cells to fetch,
+  // and the two last stages store all four of its columns or none
+  const bool lane_plain = need == 0 && (wr == 0xffu || wr == 0u);
+  const bool wave_plain = __builtin_amdgcn_ballot_w64(lane_plain) == ~0ull;
+  // passes r in [s0, s1): every stage active at a row >= 2, both last stages inside the chunk, and
+  // row r+1 still a row the sweeps read (so that the request a pass ahead stays inside the arrays)
+  int s0 = n0 + Q - 1 > Q + 1 ? n0 + Q - 1 : Q + 1;
+  s0 += s0 & 1;                                                 // a pair of passes starts at an even row
+  const int s1 = n1 + Q - 2 < p.N - 1 ? n1 + Q - 2 : p.N - 1;
+
+  RowIn x = {}, y = {};
+  typedef std::integral_constant<bool, false> general_t;
+  typedef std::integral_constant<bool, true> steady_t;
+  typedef std::integral_constant<int, 0> even_t;
+  typedef std::integral_constant<int, 1> odd_t;
+  int r = a_lo;
+  while (r <= r_end) {
+    if (wave_plain && r >= s0 && r + 2 <= s1) {
+      bload_row(r, x);
+      // (waited for here, so that inside the loop the wait for a pass's rows is the same on the way
+      // in as on the way round: "all but the nine accesses issued since", which leaves the stores out)
+      asm volatile("" :: "v"(x.a0[0]), "v"(x.ac[0]), "v"(x.bc[0]), "v"(x.upA[0]), "v"(x.upB[0]));
+      do {
+        pass(steady_t(), even_t(), r, x, y);
+        if constexpr (X == 1) pass(steady_t(), odd_t(), r + 1, x, y);
+        else pass(steady_t(), odd_t(), r + 1, y, x);
+        r += 2;
+      } while (r + 2 <= s1);
+    } else {
+      pass(general_t(), even_t(), r, x, y);
+      r++;
+    }
+  }
+  if constexpr (X == 4) {
+    if (ra.stamps && lane == 0) {
+      unsigned long long *o = ra.stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+      o[0] = t_start; o[1] = __builtin_amdgcn_s_memrealtime();
+      o[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID
+      o[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));     // XCC_ID
+    }
   }
 }
 
@@ -2303,10 +2639,16 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
   return (int)hipGetLastError();
 }
 
-// The scheduled general kernel: whole strip groups first, the rest in chunks (see launch_fused2).
-template <int S, int MINW, int H, bool NTS, bool DIV2, bool PF, bool RING = false>
-int launch_pipe_sched(const slb_multi_geom *g, const float *a0, const float *const *in, const float *const *pers_a,
-                      const float *const *pers_b, float *const *out, const float *cosines, int block, int n_chunk)
+// The scheduled general kernels: whole strip groups first, the rest in chunks (see launch_fused2).
+// `slots`: workgroups of the kernel the device holds at once (0: unknown, or n_chunk given).
+// edge_first: the two strip groups at the ends of the lattice go first, in short chunks.  Their outermost
+// waves fetch never-written cells stage by stage (a memory round trip each, five to a pass at three steps
+// per launch), which makes a pass of theirs several times as long as anyone else's; as whole strips they
+// would end long after the rest of the launch.
+template <int S>
+PipeArgs<S> make_pipe_args(const slb_multi_geom *g, const float *a0, const float *const *in, const float *const *pers_a,
+                           const float *const *pers_b, float *const *out, const float *cosines, int H, int block,
+                           int n_chunk, int slots, bool edge_first = false)
 {
   constexpr int Q = 2 * S;
   PipeArgs<S> s;
@@ -2329,11 +2671,14 @@ int launch_pipe_sched(const slb_multi_geom *g, const float *a0, const float *con
   const int wpb = block / 64;
   const int groups = (waves + wpb - 1) / wpb;
   auto chunks_of = [&](int len) { return (s.N + len - 1) / len; };
-  const int slots = n_chunk > 0 ? 0 : resident_workgroups(pipe_step_kernel<S, MINW, H, NTS, DIV2, PF, RING>, block);
-  const int whole = slots > 0 && groups >= slots ? groups / slots * slots : 0;
+  if (n_chunk > 0) slots = 0;
+  s.edge_last = 0;
+  const bool edges = edge_first && slots > 0 && groups >= slots + 2;
+  const int inner = edges ? groups - 2 : groups;          // strip groups other than the two at the ends
+  const int whole = slots > 0 && inner >= slots ? inner / slots * slots : 0;
   int tail_chunk = s.N >= 128 ? (7 * s.N + 15) / 16 : 32;
-  if (whole > 0 && whole < groups && groups < 4 * slots) {
-    int c = (slots + (groups - whole) - 1) / (groups - whole);
+  if (whole > 0 && whole < inner && inner < 4 * slots) {
+    int c = (slots + (inner - whole) - 1) / (inner - whole);
     c = c < 3 ? 3 : c;
     tail_chunk = (s.N + c - 1) / c;
     if (tail_chunk < 4 * Q) tail_chunk = s.N < 4 * Q ? s.N : 4 * Q;     // a chunk re-forms Q-1 rows above itself
@@ -2344,6 +2689,17 @@ int launch_pipe_sched(const slb_multi_geom *g, const float *a0, const float *con
     s.n_phase = 1;
     s.g0[0] = 0; s.ng[0] = groups; s.len[0] = n_chunk;
     s.wg_begin[0] = 0; s.wg_begin[1] = groups * chunks_of(n_chunk);
+  } else if (edges) {
+    if (tail_chunk > s.N) tail_chunk = s.N;
+    const int edge_chunk = s.N < 16 ? s.N : 16;
+    s.n_phase = whole < inner ? 3 : 2;
+    s.edge_last = groups - 1;
+    s.g0[0] = 0; s.ng[0] = 2; s.len[0] = edge_chunk;
+    s.wg_begin[0] = 0; s.wg_begin[1] = (2 * chunks_of(edge_chunk) + 7) / 8 * 8;
+    s.g0[1] = 1; s.ng[1] = whole; s.len[1] = s.N;
+    s.wg_begin[2] = s.wg_begin[1] + (whole + 7) / 8 * 8;
+    s.g0[2] = 1 + whole; s.ng[2] = inner - whole; s.len[2] = tail_chunk;
+    s.wg_begin[3] = s.wg_begin[2] + (inner - whole) * chunks_of(tail_chunk);
   } else {
     if (tail_chunk > s.N) tail_chunk = s.N;
     s.n_phase = whole < groups ? 2 : 1;
@@ -2353,7 +2709,36 @@ int launch_pipe_sched(const slb_multi_geom *g, const float *a0, const float *con
     s.wg_begin[2] = s.wg_begin[1] + (groups - whole) * chunks_of(tail_chunk);
   }
   for (int k = s.n_phase; k < 3; k++) { s.g0[k] = 0; s.ng[k] = 1; s.len[k] = s.N; s.wg_begin[k + 1] = s.wg_begin[k]; }
+  static const bool show = getenv("SLB_SHOW_SCHEDULE") != nullptr;
+  if (show)
+    fprintf(stderr, "slb schedule: S=%d slots=%d groups=%d phases=%d  (groups x rows) %d x %d, %d x %d, %d x %d  edge_last=%d  workgroups=%d\n",
+            S, slots, groups, s.n_phase, s.ng[0], s.len[0], s.n_phase > 1 ? s.ng[1] : 0, s.n_phase > 1 ? s.len[1] : 0,
+            s.n_phase > 2 ? s.ng[2] : 0, s.n_phase > 2 ? s.len[2] : 0, s.edge_last, s.wg_begin[s.n_phase]);
+  return s;
+}
+
+template <int S, int MINW, int H, bool NTS, bool DIV2, bool PF, bool RING = false>
+int launch_pipe_sched(const slb_multi_geom *g, const float *a0, const float *const *in, const float *const *pers_a,
+                      const float *const *pers_b, float *const *out, const float *cosines, int block, int n_chunk)
+{
+  const int slots = n_chunk > 0 ? 0 : resident_workgroups(pipe_step_kernel<S, MINW, H, NTS, DIV2, PF, RING>, block);
+  const PipeArgs<S> s = make_pipe_args<S>(g, a0, in, pers_a, pers_b, out, cosines, H, block, n_chunk, slots);
   hipLaunchKernelGGL((pipe_step_kernel<S, MINW, H, NTS, DIV2, PF, RING>), dim3(s.wg_begin[s.n_phase]), dim3(block), 0, launch_stream(), s);
+  return (int)hipGetLastError();
+}
+
+// rows: S buffers of [3][pitch] floats when ROWS, else ignored
+template <int S, int MINW, bool ROWS = false, bool DIV2 = true, int X = 0>
+int launch_ring(const slb_multi_geom *g, const float *a0, const float *const *in, const float *const *pers_a,
+                const float *const *pers_b, float *const *out, const float *cosines, int n_chunk, float *const *rows = nullptr)
+{
+  const int block = 256;                                  // the ring is laid out for four waves
+  const int slots = n_chunk > 0 ? 0 : resident_workgroups(ring_step_kernel<S, MINW, ROWS, DIV2, X>, block);
+  RingArgs<S> s;
+  s.p = make_pipe_args<S>(g, a0, in, pers_a, pers_b, out, cosines, 2, block, n_chunk, slots, true);
+  for (int i = 0; i < S; i++) s.rows[i] = ROWS && rows ? rows[i] : nullptr;
+  s.stamps = g_stamps;
+  hipLaunchKernelGGL((ring_step_kernel<S, MINW, ROWS, DIV2, X>), dim3(s.p.wg_begin[s.p.n_phase]), dim3(block), 0, launch_stream(), s);
   return (int)hipGetLastError();
 }
 
@@ -2427,6 +2812,9 @@ void slb_pop_stream(void)
 }
 void slb_set_av_mode(int mode)         { g_av_mode = (mode == SLB_AV_TREE || mode == SLB_AV_CHAIN) ? mode : SLB_AV_EXACT; }
 void slb_set_tuning(int v, int nc, int b) { g_variant = v; g_n_chunk = nc; g_block = b; }
+#ifdef SLB_TIMING_VARIANTS
+void slb_debug_set_stamps(unsigned long long *buf) { g_stamps = buf; }
+#endif
 const char *slb_version(void)          { return "slb2d-gfx950 0.1"; }
 
 int slb_sweep(const slb_slab *slab,
@@ -2820,6 +3208,28 @@ int slb_step_multi(const slb_multi_geom *g, const float *a0, const float *const 
       case 381: return launch_pipe_sched<3, 2, 2, true, true, false, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
       case 382: return launch_pipe_sched<3, 3, 2, true, true, true, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
       case 383: return launch_pipe_sched<3, 2, 2, true, true, true, true>(g, a0, in, pers_a, pers_b, out, cosines, block, nc);
+      default: break;
+    }
+  }
+  // tuning variants 90 / 91: the ring kernel with the branch-free steady passes (ring_step_kernel),
+  // register budget of 2 / 3 waves per SIMD
+#ifdef SLB_TIMING_VARIANTS
+  if (v == 97 && g->steps == 3) return launch_ring<3, 2, false, true, 6>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
+  if (v == 95 && g->steps == 3) return launch_ring<3, 2, false, true, 4>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
+  if (v == 96 && g->steps == 3) return launch_ring<3, 2, false, true, 5>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
+  if (v >= 92 && v <= 94 && g->steps == 3) {
+    if (v == 92) return launch_ring<3, 2, false, true, 1>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
+    if (v == 93) return launch_ring<3, 2, false, true, 2>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
+    if (v == 94) return launch_ring<3, 2, false, true, 3>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
+  }
+#endif
+  if ((v == 90 || v == 91) && (g->steps == 2 || g->steps == 3)) {
+    if (block != 256) { fprintf(stderr, "slb_step_multi: the LDS ring is laid out for 256 threads\n"); return -1; }
+    const int nc = g_n_chunk;
+    switch (g->steps * 100 + v) {
+      case 290: return launch_ring<2, 2>(g, a0, in, pers_a, pers_b, out, cosines, nc);
+      case 291: return launch_ring<2, 3>(g, a0, in, pers_a, pers_b, out, cosines, nc);
+      case 390: return launch_ring<3, 2>(g, a0, in, pers_a, pers_b, out, cosines, nc);
       default: break;
     }
   }
