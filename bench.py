@@ -45,6 +45,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
 BYTES_PER_POINT_SWEEP = 28     # two-sweep form: 5 fp32 reads + 2 fp32 writes per point per sweep
 BYTES_PER_UPDATE_FUSED = 36    # one-launch step: 5 reads + 4 writes per lattice-point-update
 BYTES_PER_UPDATE_DOUBLE = 18   # two steps per launch: the same 9 accesses serve two updates
+BYTES_PER_UPDATE_TRIPLE = 12   # three steps per launch: ... three updates
 TRAFFIC_FILE = os.path.join("profiles", "hbm_traffic.json")
 
 
@@ -141,8 +142,11 @@ def parse_args(argv=None):
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--n-chunk", type=int, default=0)
     ap.add_argument("--block", type=int, default=0)
-    ap.add_argument("--form", choices=("double", "fused", "sweeps"), default="double",
-                    help="double: two steps (four sweeps) per launch (default); "
+    ap.add_argument("--form", choices=("auto", "triple", "double", "fused", "sweeps"), default="auto",
+                    help="triple: three steps (six sweeps) per launch, a remainder of the K steps in a "
+                         "double and a single step (default on one GPU); "
+                         "double: two steps (four sweeps) per launch (default on several GPUs: the form "
+                         "the slab driver runs); "
                          "fused: both sweeps of a step in one launch; "
                          "sweeps: the reference's two launches per step")
     ap.add_argument("--driver", choices=("auto", "c", "torch"), default="auto",
@@ -177,6 +181,8 @@ def alg_bytes_per_launch(form, n_harm, cols):
     """Algorithmic bytes of the dominant kernel's launch on `cols` grid columns: the main sweep
     covers cols+1 columns and the half-step sweep cols, hence the half column."""
     points = n_harm * (cols + 0.5)
+    if form == "triple":       # one launch = three steps, the same 9 array passes
+        return "ring_step_kernel", 3 * BYTES_PER_UPDATE_TRIPLE * points
     if form == "double":       # one launch = two steps, the same 9 array passes
         return "fused2_step_kernel", 2 * BYTES_PER_UPDATE_DOUBLE * points
     if form == "fused":
@@ -209,6 +215,8 @@ def roofline(form, n_harm, cols, kernel_ms, traffic=None, traffic_source=None):
 
 
 def launches_per(form, steps):
+    if form == "triple":
+        return steps // 3 + (steps % 3 + 1) // 2
     return {"double": steps // 2 + steps % 2, "fused": steps, "sweeps": 2 * steps}[form]
 
 
@@ -221,9 +229,9 @@ def median_block(blocks):
 def run_single(args, slb, torch, form, steps, warmup, repeats):
     sol = slb.Solver(0, 1)
     sol.tiptoe()
-    sol.set_fused({"double": 2, "fused": 1, "sweeps": 0}[form])
+    sol.set_fused({"triple": 3, "double": 2, "fused": 1, "sweeps": 0}[form])
     warm = warmup
-    if form == "double":
+    if form in ("double", "triple"):
         # an even number of warm-up steps keeps the ping-pong parity the spare arrays were
         # made for (an odd count would re-copy them inside the timed region)
         warm += warm % 2
@@ -237,6 +245,12 @@ def run_single(args, slb, torch, form, steps, warmup, repeats):
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         blocks.append((wall, ev_ms / launches_per(form, steps)))   # launches are back to back
+    if form == "triple" and steps % 3:
+        # the dominant kernel's own launch time: blocks of three-step launches only, same events
+        n3 = 2 * max(steps // 6, 1)
+        pure = sorted(sol.run_timed(3 * n3) / n3 for _ in range(max(repeats, 3)))
+        k3 = pure[(len(pure) - 1) // 2]
+        blocks = [(w, k3) for w, _ in blocks]
     sol.close()
     return blocks
 
@@ -320,6 +334,10 @@ def main():
     backend = os.environ.get("SLB_DIST_BACKEND", "nccl")
     ranks_seen = 1
     driver = None
+    if args.form == "auto":
+        args.form = "triple" if world == 1 else "double"
+    if world > 1 and args.form == "triple":
+        raise SystemExit("--form triple runs on one GPU (the slab driver takes two steps per launch)")
     if world > 1:
         driver = args.driver
         if driver == "auto":
@@ -420,8 +438,8 @@ def main():
     walls = [b[0] for b in blocks]
     updates = float(n_harm) * float(g_grid) * args.steps
     value = updates / wall
-    bytes_per_update = {"double": BYTES_PER_UPDATE_DOUBLE, "fused": BYTES_PER_UPDATE_FUSED,
-                        "sweeps": 2 * BYTES_PER_POINT_SWEEP}[args.form]
+    bytes_per_update = {"triple": BYTES_PER_UPDATE_TRIPLE, "double": BYTES_PER_UPDATE_DOUBLE,
+                        "fused": BYTES_PER_UPDATE_FUSED, "sweeps": 2 * BYTES_PER_POINT_SWEEP}[args.form]
     out = {
         "metric": "lattice-point-updates/sec (n-harmonics x g-grid per step)",
         "value": value, "unit": "lattice-point-updates/s",
@@ -458,6 +476,18 @@ def main():
             if world > 1:
                 out["roofline"]["note"] = ("rank 0's slab; stream time per double step including waits "
                                            "for halo columns, not the bare kernel")
+            elif args.form == "triple":
+                out["roofline"]["note"] = ("the kernel is bound by vector-instruction issue, not by HBM: the fraction says how "
+                                           "much of the HBM peak its 12 B per update use; avg_launch_ms is measured over "
+                                           "blocks of three-step launches only (HIP events on the launch stream)")
+        if world == 1 and args.form == "triple" and not args.no_two_sweep:
+            # the two-steps-per-launch kernel (the slab driver's form, last round's default), same process
+            bd = run_single(args, slb, torch, "double", 20, 2, 3)
+            wd, kd = median_block(bd)
+            td, sd = recorded_traffic("double", n_harm, g_grid)
+            dbl = roofline("double", n_harm, g_grid, kd, td, sd)
+            dbl.update({"steps": 20, "repeats": 3, "value": n_harm * g_grid * 20 / wd, "ms_per_step": wd / 20 * 1e3})
+            out["double_step"] = dbl
         if world == 1 and args.form != "sweeps" and not args.no_two_sweep:
             # the reference's own formulation (two launches per step, 28 B per point per sweep),
             # timed in the same process

@@ -229,6 +229,15 @@ int slb_step_multi(const slb_multi_geom *geom, const float *a0, const float *con
                    const float *const pers_a[], const float *const pers_b[], float *const out[4],
                    const float cosines[]);
 
+/* The same for S = 1..3, also writing the rows av() reads -- a rows 0 and 1, b row 1 -- of the
+ * main lattice after EACH of the S iterations into rows[i] (i = 0..S-1; device, [3][pitch]
+ * floats each, a row 0 first), at the columns the launch forms: the lattices in between are
+ * stored nowhere else, so this is what lets the averaging period (reference:
+ * src/boltzmann_c_solver.c:188-191) keep S iterations per launch. */
+int slb_step_multi_rows(const slb_multi_geom *geom, const float *a0, const float *const in[4],
+                        const float *const pers_a[], const float *const pers_b[], float *const out[4],
+                        const float cosines[], float *const rows[]);
+
 /* Gather local columns col..col+ncols-1 of rows 0..nrows-1 of arrays a and b
  * into buf (a's columns first, each column contiguous: buf[(q*ncols + c)*nrows + r],
  * q = 0 for a, 1 for b); and the inverse scatter.  buf holds 2*ncols*nrows floats. */
@@ -369,9 +378,14 @@ void  slb_pop_stream(void);
  *   slb_step_fused2_factored loads a0 like slb_step_fused2_rows unless asked otherwise (forming
  *   it measured slower on MI355X): 50 = a0 formed from the factors once per row and handed from
  *   stage to stage, 51 = every stage forms the a0 values of its own row.
- *   slb_step_multi: 32 / 33 / 34 = two columns per lane instead of four, with a
- *   register budget of 2 / 3 / 4 waves per SIMD; 35 / 36 / 37 = one column per lane, budget
- *   of 2 / 4 / 8 waves per SIMD.
+ *   64 = the compiler's own point update (default: two columns at a time with one reciprocal for
+ *   the two quotients of a point, where the run's denominators lie between 0.5 and 2^100).
+ *   slb_step_multi (default at three steps per launch: the LDS-ring kernel with branch-free steady
+ *   passes): 1 = the register-history kernel at any S; 32 / 33 / 34 = that kernel with two columns
+ *   per lane instead of four, with a register budget of 2 / 3 / 4 waves per SIMD; 35 / 36 / 37 = one
+ *   column per lane, budget of 2 / 4 / 8 waves per SIMD; 70..75 = the scheduled kernel with its
+ *   stage outputs in registers, 80..84 = in an LDS ring per wave (S = 2, 3); 90 / 91 = the ring
+ *   kernel with branch-free steady passes at S = 2 (budget of 2 / 3 waves per SIMD) and S = 3.
  *   slb_seq_sum: 41..47 = other workgroup shapes.
  * n_chunk = rows per workgroup in n (0: by lattice width), block = threads (0: 256). */
 void slb_set_tuning(int variant, int n_chunk, int block);

@@ -24,7 +24,7 @@ _INT_GLOBALS = ("host_M", "host_N", "MSIZE", "MP1", "NSIZE", "host_TMSIZE", "PAD
 
 # every symbol include/slb_abi.h declares
 ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "HandleError",
-                 "slb_sweep", "slb_step_fused", "slb_step_fused2", "slb_step_fused2_rows", "slb_step_multi",
+                 "slb_sweep", "slb_step_fused", "slb_step_fused2", "slb_step_fused2_rows", "slb_step_multi", "slb_step_multi_rows",
                  "slb_av_sums_exact", "slb_av_sums_exact_n", "slb_av_sums_exact_from_n", "slb_av_update_exact", "slb_halo_pack", "slb_halo_unpack", "slb_halo_pack_segs", "slb_halo_unpack_segs", "slb_av_partial",
                  "slb_frame_values", "slb_seq_sum", "slb_seq_sum_stats",
                  "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream", "slb_push_stream", "slb_pop_stream",
@@ -113,6 +113,10 @@ def lib():
         L.slb_step_multi.argtypes = [C.POINTER(MultiGeom), fp, C.POINTER(C.c_void_p * 4), C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p * 4), C.POINTER(C.c_float)]
         L.slb_step_multi.restype = i
+        L.slb_step_multi_rows.argtypes = [C.POINTER(MultiGeom), fp, C.POINTER(C.c_void_p * 4), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p * 4), C.POINTER(C.c_float),
+                                          C.POINTER(C.c_void_p)]
+        L.slb_step_multi_rows.restype = i
         L.slb_static_init.argtypes, L.slb_static_init.restype = [], i
         L.slb_av_static.argtypes, L.slb_av_static.restype = [fp, fp, fp, f], i
         L.slb_halo_pack.argtypes = [fp, fp, i, i, i, i, fp]
@@ -173,6 +177,11 @@ def lib():
         L.slb_solver_multi_step_finish.argtypes = [C.POINTER(SolverStruct), i]
         L.slb_solver_multi_step_finish.restype = None
         L.slb_steps_cosines.argtypes, L.slb_steps_cosines.restype = [f, i, C.POINTER(C.c_float)], None
+        L.slb_solver_multi_step_rows.argtypes = [C.POINTER(SolverStruct), i, C.POINTER(C.c_void_p)]
+        L.slb_solver_multi_step_rows.restype = None
+        L.slb_solver_multi_step_range_rows.argtypes = [C.POINTER(SolverStruct), i, i, i, C.POINTER(C.c_float), C.POINTER(C.c_void_p)]
+        L.slb_solver_multi_step_range_rows.restype = None
+        L.slb_solver_steps_per_launch.argtypes, L.slb_solver_steps_per_launch.restype = [C.POINTER(SolverStruct)], i
         L.slb_step2_cosines.argtypes, L.slb_step2_cosines.restype = [f, C.POINTER(C.c_float * 8)], None
         L.slb_solver_step_fused_range.argtypes = [C.POINTER(SolverStruct), i, i, C.POINTER(C.c_float * 4)]
         L.slb_solver_step_fused_range.restype = None
@@ -302,9 +311,22 @@ class Solver:
     def multi_step(self, S):
         lib().slb_solver_multi_step(self._p, S)
 
-    def multi_step_range(self, S, j_first, j_last, cosines):
+    def multi_step_rows(self, S, rows):
+        """rows: S device pointers to [3][pitch] buffers that receive the rows av() reads of the
+        main lattice after each of the S iterations."""
+        r = (C.c_void_p * S)(*rows)
+        lib().slb_solver_multi_step_rows(self._p, S, r)
+
+    def steps_per_launch(self):
+        return lib().slb_solver_steps_per_launch(self._p)
+
+    def multi_step_range(self, S, j_first, j_last, cosines, rows=None):
         c = (C.c_float * (4 * S))(*cosines)
-        lib().slb_solver_multi_step_range(self._p, S, j_first, j_last, c)
+        if rows is None:
+            lib().slb_solver_multi_step_range(self._p, S, j_first, j_last, c)
+        else:
+            r = (C.c_void_p * S)(*rows)
+            lib().slb_solver_multi_step_range_rows(self._p, S, j_first, j_last, c, r)
 
     def multi_step_finish(self, S):
         lib().slb_solver_multi_step_finish(self._p, S)
@@ -322,7 +344,8 @@ class Solver:
         lib().slb_solver_double_step_finish(self._p)
 
     def set_fused(self, on):
-        """0/False: two launches per step; 1/True: one launch per step; 2: one launch per two steps."""
+        """0/False: two launches per step; 1/True: one launch per step; 2: one launch per two steps;
+        3: one launch per three steps (the rest of a run in twos and ones); 10 + S: slb_step_multi with S."""
         self._p.contents.fused = int(on)
 
     def sweep_main(self, c0, c1):

@@ -1713,8 +1713,6 @@ ring_step_kernel(const RingArgs<S> ra)
   if (p.jj0 + wave * INNER * V > j_hi) return;                  // whole wave past the end
   unsigned long long t_start = 0;
   if constexpr (X == 4) t_start = __builtin_amdgcn_s_memrealtime();
-  if constexpr (X == 5) __builtin_amdgcn_s_sleep(0), __builtin_amdgcn_s_sleep(0);
-  if constexpr (X == 5) { for (int i = (blockIdx.x * 5 + (threadIdx.x >> 6) * 3) & 15; i > 0; i--) __builtin_amdgcn_s_sleep(16); }
   const bool interior = lane >= H && lane < 64 - H;
   const int jcl = jj < 0 ? 0 : (jj > p.pitch - V ? p.pitch - V : jj);
   const unsigned j = (unsigned)jcl;
@@ -1855,10 +1853,10 @@ ring_step_kernel(const RingArgs<S> ra)
             cb = slb_f2{oldB[q >= 2 ? q - 2 : 0][k], oldB[q >= 2 ? q - 2 : 0][k + 1]};
           }
           const slb_f2 a0v = q == 0 ? slb_f2{a0r[k], a0r[k + 1]} : slb_f2{a0h[q >= 1 ? q - 1 : 0][k], a0h[q >= 1 ? q - 1 : 0][k + 1]};
-          // (the field terms are the same in every pass; formed here all the same, behind a fence the
-          // optimiser cannot see through, because carried across the loop they would cost 8 S registers)
-          slb_f2 bp = {bphi[k], bphi[k + 1]};
-          if constexpr (ST && X != 6) asm volatile("" : "+v"(bp));
+          // (the field terms are the same in every pass: in the branch-free body the optimiser carries
+          // them across the loop in 8 S registers -- 9 % fewer vector instructions per pass, and the
+          // kernel's time follows its vector instructions, not its bytes)
+          const slb_f2 bp = {bphi[k], bphi[k + 1]};
           const slb_f2 mu_a = (sc[2 * q] + bp) * p.dt / 2.0f, mu_b = (sc[2 * q + 1] + bp) * p.dt / 2.0f;
           slb_f2 qa, qb;
           point_update_pair<DIV2>(p, fn, mu_a, mu_b, a0v, ca, cb, slb_f2{ea[k + 2], ea[k + 3]}, slb_f2{ea[k], ea[k + 1]},
@@ -1870,7 +1868,7 @@ ring_step_kernel(const RingArgs<S> ra)
         if constexpr (ST) {
           // (one stage at a time: left to itself the scheduler interleaves the stages of the branch-free
           // body for parallelism it has no registers for)
-          if constexpr (X != 3) __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(0);
           if (q >= Q - 2 && X != 2) {
             bstore4(q == Q - 2 ? p.a_o : p.a_ho, row, nA[q]);
             bstore4(q == Q - 2 ? p.b_o : p.b_ho, row, nB[q]);
@@ -2728,6 +2726,20 @@ int launch_pipe_sched(const slb_multi_geom *g, const float *a0, const float *con
 }
 
 // rows: S buffers of [3][pitch] floats when ROWS, else ignored
+// May the two quotients of a point share one reciprocal (div2_shared)?  Their denominator is
+// nu^2 + mu_t1^2 with |mu_t1| <= N (|E_dc| + |E_omega| + |B| max|phi_y|) dt / 2; the shared form equals
+// the compiler's division for denominators from 0.5 to 2^100 (slb_selftest_division).
+bool shared_division_ok(int m_offset, int pitch)
+{
+  const double phi_lo = (double)g_phys.PhiYmin + (double)g_phys.dPhi * (double)(m_offset - 1);
+  const double phi_hi = (double)g_phys.PhiYmin + (double)g_phys.dPhi * (double)(m_offset + pitch);
+  const double phi = fabs(phi_lo) > fabs(phi_hi) ? fabs(phi_lo) : fabs(phi_hi);
+  const double mu1 = (double)g_phys.N * (fabs((double)g_phys.E_dc) + fabs((double)g_phys.E_omega) + fabs((double)g_phys.B) * phi) *
+                     fabs((double)g_phys.dt) * 0.5 * 1.0001;
+  const double lo = (double)g_phys.nu2, hi = (double)g_phys.nu2 + mu1 * mu1;
+  return lo >= 0.5 && hi <= 0x1p100 && hi == hi;      // (NaN parameters fail the last test)
+}
+
 template <int S, int MINW, bool ROWS = false, bool DIV2 = true, int X = 0>
 int launch_ring(const slb_multi_geom *g, const float *a0, const float *const *in, const float *const *pers_a,
                 const float *const *pers_b, float *const *out, const float *cosines, int n_chunk, float *const *rows = nullptr)
@@ -3112,9 +3124,16 @@ static int step_fused2_impl(const slb_step2_geom *g, const float *a0, const doub
   if (g_variant == 63)
     return rows_first ? launch_fused2<3, false, true, 2, true, false, 0, 7>(s, block, n_chunk, tail_chunk)
                       : launch_fused2<3, false, false, 2, true, false, 0, 7>(s, block, n_chunk, tail_chunk);
-  if (rows_first) return launch_fused2<3, false, true>(s, block, n_chunk, tail_chunk);
   // default: two halo lanes per side (the 60 interior lanes' stores start on 64-byte boundaries),
-  // non-temporal stores, registers for 3 waves per SIMD.  The rest are tuning variants.
+  // non-temporal stores, registers for 3 waves per SIMD, the point update two columns wide with one
+  // reciprocal for the two quotients of a point where the denominators allow it (measured on MI355X:
+  // 1.004-1.009 against 1.014-1.042 ms at 128 x 2^20, 0.150 against 0.174-0.184 ms at 64 x 2^18;
+  // tuning variant 64 = the compiler's own point update).  The rest are tuning variants.
+  const bool fast_point = g_variant != 64 && shared_division_ok(g->m_offset, g->pitch);
+  if (rows_first) return fast_point ? launch_fused2<3, false, true, 2, true, false, 0, 7>(s, block, n_chunk, tail_chunk)
+                                    : launch_fused2<3, false, true>(s, block, n_chunk, tail_chunk);
+  if (fast_point && (g_variant == 0 || g_variant == 26 || g_variant == 34 || g_variant == 38 || g_variant == 39))
+    return launch_fused2<3, false, false, 2, true, false, 0, 7>(s, block, n_chunk, tail_chunk);
   switch (g_variant) {
     case 20: return launch_fused2<3, false, false, 1, false>(s, block, n_chunk, tail_chunk);  // one halo lane, plain stores
     case 21: return launch_fused2<2, false, false, 1, false>(s, block, n_chunk, tail_chunk);  // register budget of 2, 4 waves per SIMD
@@ -3131,9 +3150,31 @@ static int step_fused2_impl(const slb_step2_geom *g, const float *a0, const doub
   }
 }
 
+static int step_multi_impl(const slb_multi_geom *g, const float *a0, const float *const in[4],
+                           const float *const pers_a[], const float *const pers_b[], float *const out[4],
+                           const float cosines[], float *const rows[]);
+
 int slb_step_multi(const slb_multi_geom *g, const float *a0, const float *const in[4],
                    const float *const pers_a[], const float *const pers_b[], float *const out[4],
                    const float cosines[])
+{
+  return step_multi_impl(g, a0, in, pers_a, pers_b, out, cosines, nullptr);
+}
+
+int slb_step_multi_rows(const slb_multi_geom *g, const float *a0, const float *const in[4],
+                        const float *const pers_a[], const float *const pers_b[], float *const out[4],
+                        const float cosines[], float *const rows[])
+{
+  if (!g || !rows) { fprintf(stderr, "slb_step_multi_rows: one row buffer per iteration is needed\n"); return -1; }
+  if (g->steps < 1 || g->steps > 3) { fprintf(stderr, "slb_step_multi_rows: 1 to 3 steps per launch\n"); return -1; }
+  for (int i = 0; i < g->steps; i++)
+    if (!rows[i]) { fprintf(stderr, "slb_step_multi_rows: one row buffer per iteration is needed\n"); return -1; }
+  return step_multi_impl(g, a0, in, pers_a, pers_b, out, cosines, rows);
+}
+
+static int step_multi_impl(const slb_multi_geom *g, const float *a0, const float *const in[4],
+                           const float *const pers_a[], const float *const pers_b[], float *const out[4],
+                           const float cosines[], float *const rows[])
 {
   if (!g_phys.loaded) { fprintf(stderr, "slb_step_multi: load_data() has not been called\n"); return -1; }
   if (!g || g->steps < 1 || g->steps > 4 || g->pitch < 4 || g->pitch % 4 != 0 || g_phys.N < 1) {
@@ -3214,14 +3255,10 @@ int slb_step_multi(const slb_multi_geom *g, const float *a0, const float *const 
   // tuning variants 90 / 91: the ring kernel with the branch-free steady passes (ring_step_kernel),
   // register budget of 2 / 3 waves per SIMD
 #ifdef SLB_TIMING_VARIANTS
-  if (v == 97 && g->steps == 3) return launch_ring<3, 2, false, true, 6>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
+  // timing builds: 92 = the rows of a pass requested in that pass, 93 = no stores, 95 = time stamps per wave
+  if (v == 92 && g->steps == 3) return launch_ring<3, 2, false, true, 1>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
+  if (v == 93 && g->steps == 3) return launch_ring<3, 2, false, true, 2>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
   if (v == 95 && g->steps == 3) return launch_ring<3, 2, false, true, 4>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
-  if (v == 96 && g->steps == 3) return launch_ring<3, 2, false, true, 5>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
-  if (v >= 92 && v <= 94 && g->steps == 3) {
-    if (v == 92) return launch_ring<3, 2, false, true, 1>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
-    if (v == 93) return launch_ring<3, 2, false, true, 2>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
-    if (v == 94) return launch_ring<3, 2, false, true, 3>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
-  }
 #endif
   if ((v == 90 || v == 91) && (g->steps == 2 || g->steps == 3)) {
     if (block != 256) { fprintf(stderr, "slb_step_multi: the LDS ring is laid out for 256 threads\n"); return -1; }
@@ -3245,6 +3282,23 @@ int slb_step_multi(const slb_multi_geom *g, const float *a0, const float *const 
       case 41: return launch_multi<4, 1, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);
       default: break;
     }
+  }
+  // Three steps per launch: the LDS-ring kernel (ring_step_kernel), the fastest form on MI355X from about
+  // one round of workgroups up (tuning variant 1 keeps the register-history kernel, multi_step_kernel).
+  // With rows, the ring kernel is the only three-step form that hands them out.
+  if (g->steps == 3 && block == 256 && (v == 0 || rows)) {
+    const int nc = g_n_chunk;
+    const bool d2 = shared_division_ok(g->m_offset, g->pitch);
+    if (rows) return d2 ? launch_ring<3, 2, true, true>(g, a0, in, pers_a, pers_b, out, cosines, nc, rows)
+                        : launch_ring<3, 2, true, false>(g, a0, in, pers_a, pers_b, out, cosines, nc, rows);
+    return d2 ? launch_ring<3, 2, false, true>(g, a0, in, pers_a, pers_b, out, cosines, nc)
+              : launch_ring<3, 2, false, false>(g, a0, in, pers_a, pers_b, out, cosines, nc);
+  }
+  if (rows) {
+    if (g->steps == 1) return launch_multi<1, 4, 4, false, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk, nullptr, rows[0]);
+    if (g->steps == 2) return launch_multi<2, 4, 3, false, true>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk, rows[0], rows[1]);
+    fprintf(stderr, "slb_step_multi_rows: three steps per launch hand out rows with 256-thread workgroups only\n");
+    return -1;
   }
   switch (g->steps) {
     case 1: return launch_multi<1, 4, 4>(g, a0, in, pers_a, pers_b, out, cosines, block, n_chunk);

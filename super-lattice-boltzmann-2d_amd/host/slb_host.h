@@ -127,6 +127,13 @@ void slb_solver_double_step_finish(slb_solver *s);
 void slb_solver_multi_step(slb_solver *s, int S);
 void slb_solver_multi_step_range(slb_solver *s, int S, int j_first, int j_last, const float *c);
 void slb_solver_multi_step_finish(slb_solver *s, int S);
+/* the same (S <= 3), also writing the rows av() reads of each of the S new main lattices into
+ * rows[0..S-1] ([3][pitch] device buffers: a row 0, a row 1, b row 1) */
+void slb_solver_multi_step_rows(slb_solver *s, int S, float *const *rows);
+void slb_solver_multi_step_range_rows(slb_solver *s, int S, int j_first, int j_last, const float *c, float *const *rows);
+/* iterations per launch the time loop should use on this slab (3 on wide lattices, else 2;
+ * SLB_STEPS_PER_LAUNCH overrides) */
+int  slb_solver_steps_per_launch(const slb_solver *s);
 /* cosines of S consecutive iterations starting at t, 4 per iteration */
 void slb_steps_cosines(float t, int S, float *c);
 /* cosines of two consecutive iterations starting at t (see slb_step_cosines) */

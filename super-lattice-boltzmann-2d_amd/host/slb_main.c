@@ -370,20 +370,21 @@ static void av_ring_flush(slb_solver *s)
   av_n_pending = 0;
 }
 
-/* the next n (1 or 2) slots' rows have been queued on the time loop's stream: queue their
+/* the next n (1 to 3) slots' rows have been queued on the time loop's stream: queue their
  * sums (one launch) and their updates of av_data for the loop times t[0..n-1] */
 static void av_ring_submit(slb_solver *s, int n, const float *t)
 {
   if (!av_tree) {
+    if (av_n_pending + n > AV_BATCH) av_ring_flush(s);
     for (int i = 0; i < n; i++) {
       av_pending[av_n_pending].slot = (int)((av_index + i) % AV_SLOTS);
       av_pending[av_n_pending].t = t[i];
       av_n_pending++;
     }
     av_index += n;
-    /* out at once when nothing is running; otherwise when a full launch has gathered (two
+    /* out at once when nothing is running; otherwise when a full launch has gathered (three
      * more lattices would not fit) */
-    if (av_n_pending + 2 > AV_BATCH || !av_batch_out || hipEventQuery(ev_batch) == hipSuccess) av_ring_flush(s);
+    if (av_n_pending + 3 > AV_BATCH || !av_batch_out || hipEventQuery(ev_batch) == hipSuccess) av_ring_flush(s);
     return;
   }
   /* tree sums: short launches that share a workspace; sums and update of each step in turn */
@@ -475,10 +476,13 @@ int slb_main(int argc, char **argv)
   float av6[6] = {0, 0, 0, 0, 0, 0};
 
   /* SLB_FORM=sweeps selects the reference's two launches per step, SLB_FORM=fused
-   * one launch per step; default: one launch per two steps where the loop allows */
+   * one launch per step, SLB_FORM=double one launch per two steps; default: one launch per
+   * three steps on lattices wide enough for that kernel (slb_solver_steps_per_launch), per two
+   * otherwise, wherever the loop allows */
   const char *form = getenv("SLB_FORM");
   const int two_launches = form != NULL && strcmp(form, "sweeps") == 0;
   const int one_launch   = form != NULL && strcmp(form, "fused") == 0;
+  const int triples = !(form != NULL && strcmp(form, "double") == 0) && slb_solver_steps_per_launch(s) == 3;
 
   /* SLB_AV=tree: wave64 tree reduction for av() (about 10 us) instead of the default
    * exact-order sums (bit-identical to the CPU solver; about 1 ms at g-grid 2^20);
@@ -507,6 +511,36 @@ int slb_main(int argc, char **argv)
       if (!two_launches && !one_launch) {
         const float t2 = t + host_dt, ft2 = frame_time + host_dt;
         const int k1 = step_kind(t, frame_time), k2 = step_kind(t2, ft2);
+        /* three iterations in one launch likewise */
+        const float t3 = t2 + host_dt, ft3 = ft2 + host_dt;
+        const int k3 = step_kind(t3, ft3);
+        if (triples && k1 < 2 && k2 < 2 && k3 < 2 && t2 < t_max && t3 < t_max) {
+          s->t = t;
+          if (k1 == 0 && k2 == 0 && k3 == 0) {
+            slb_solver_multi_step(s, 3);
+          } else {
+            /* av() after every iteration from t_start on: the iterations before it leave their rows
+             * in slots nobody reads (the ones the next launches will use) */
+            const int kk[3] = {k1, k2, k3};
+            const float tk[3] = {t, t2, t3};
+            const int n_av = k1 + k2 + k3;
+            float *rows[3], tt[3];
+            int used = 0;
+            for (int i = 0; i < 3; i++) if (kk[i]) { tt[used] = tk[i]; rows[i] = av_ring_acquire(s, used++); }
+            for (int i = 0, spare = n_av; i < 3; i++) if (!kk[i]) rows[i] = av_ring_acquire(s, spare++);
+            slb_solver_multi_step_rows(s, 3, rows);
+            av_ring_submit(s, n_av, tt);
+          }
+          t = t3;
+          loop_steps += 2;
+          frame_time = ft3 + host_dt;
+          if (out != stdout && display != 7 && quiet == 0 && (progress += 3) >= 300) {
+            printf("\rt=%0.9f %0.2f%%", t, t / t_max * 100);
+            fflush(stdout);
+            progress = 0;
+          }
+          continue;
+        }
         if (k1 < 2 && k2 < 2 && t2 < t_max) {
           s->t = t;                      /* the engine forms both iterations' cosines from its own clock */
           if (k1 == 0 && k2 == 0) {

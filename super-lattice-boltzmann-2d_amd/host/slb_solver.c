@@ -505,6 +505,13 @@ void slb_solver_double_step_rows(slb_solver *s, float *rows_first, float *rows_s
  * current.  c = the cosines of the S loop times, 4 per iteration. */
 void slb_solver_multi_step_range(slb_solver *s, int S, int j_first, int j_last, const float *c)
 {
+  slb_solver_multi_step_range_rows(s, S, j_first, j_last, c, NULL);
+}
+
+/* the same, also writing the rows av() reads of the S new main lattices into rows[0..S-1]
+ * ([3][pitch] device buffers; S <= 3) at the columns this range forms; rows == NULL: none */
+void slb_solver_multi_step_range_rows(slb_solver *s, int S, int j_first, int j_last, const float *c, float *const *rows)
+{
   if (S < 1 || S > 4) { fprintf(stderr, "slb_solver_multi_step: 1 to 4 steps per launch\n"); exit(EXIT_FAILURE); }
   const int Q = 2 * S, even = (S % 2) == 0;
   if (even && (!s->spare_a || s->spare_of != s->current || s->spare_of_hs != s->current_hs)) sync_spares(s);
@@ -539,7 +546,8 @@ void slb_solver_multi_step_range(slb_solver *s, int S, int j_first, int j_last, 
     pa[q] = s->a[idx]; pb[q] = s->b[idx];
   }
   pa[Q - 2] = out[0]; pb[Q - 2] = out[1];
-  { int rc_; ON(s, rc_ = slb_step_multi(&g, s->a0, in, pa, pb, out, c)); check_sweep(rc_, __LINE__); }
+  if (rows) { int rc_; ON(s, rc_ = slb_step_multi_rows(&g, s->a0, in, pa, pb, out, c, rows)); check_sweep(rc_, __LINE__); }
+  else      { int rc_; ON(s, rc_ = slb_step_multi(&g, s->a0, in, pa, pb, out, c)); check_sweep(rc_, __LINE__); }
 }
 
 void slb_solver_multi_step_finish(slb_solver *s, int S)
@@ -572,6 +580,26 @@ void slb_solver_multi_step(slb_solver *s, int S)
   slb_solver_multi_step_finish(s, S);
 }
 
+void slb_solver_multi_step_rows(slb_solver *s, int S, float *const *rows)
+{
+  float c[16];
+  slb_steps_cosines(s->t, S, c);
+  slb_solver_multi_step_range_rows(s, S, s->half_slab.j_first, s->half_slab.j_last, c, rows);
+  slb_solver_multi_step_finish(s, S);
+}
+
+/* How many loop iterations a launch of the time loop should take on this slab: 3 where the
+ * three-step kernel has the lattice to fill the device (its lanes own four columns; measured on
+ * MI355X it passes the double step from about 2^19 columns at 64 harmonics up), else 2.
+ * SLB_STEPS_PER_LAUNCH=1..3 overrides. */
+int slb_solver_steps_per_launch(const slb_solver *s)
+{
+  const char *e = getenv("SLB_STEPS_PER_LAUNCH");
+  if (e && e[0] >= '1' && e[0] <= '3' && e[1] == 0) return e[0] - '0';
+  const long waves = ((long)s->W + 239) / 240;
+  return s->N >= 48 && waves >= 2048 ? 3 : 2;
+}
+
 int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
 {
   hipStream_t st = stream_of(s);
@@ -580,7 +608,10 @@ int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
   HIP_OK(hipEventCreate(&e1));
   HIP_OK(hipEventRecord(e0, st));
   int i = 0;
-  if (s->fused == 2) {
+  if (s->fused == 3) {                       /* three steps per launch, the rest in twos and ones */
+    for (; i + 2 < steps; i += 3) slb_solver_multi_step(s, 3);
+    for (; i + 1 < steps; i += 2) slb_solver_double_step(s);
+  } else if (s->fused == 2) {
     for (; i + 1 < steps; i += 2) slb_solver_double_step(s);
   } else if (s->fused >= 10) {               /* 10 + S: the general S-steps-per-launch kernel */
     const int S = s->fused - 10;

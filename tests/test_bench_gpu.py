@@ -1,4 +1,4 @@
-"""The bench contract: one JSON line with the agreed keys, for the three step forms."""
+"""The bench contract: one JSON line with the agreed keys, for the four step forms."""
 import json
 import os
 import subprocess
@@ -11,10 +11,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("form", ["double", "fused", "sweeps"])
+@pytest.mark.parametrize("form", ["triple", "double", "fused", "sweeps"])
 def test_bench_prints_one_json_line(form):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
-                        "--form", form, "--no-cpu", "--g-grid-per-gpu", "65536"],
+                        "--no-cpu", "--g-grid-per-gpu", "65536"] + ([] if form == "triple" else ["--form", form]),
                        capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -41,6 +41,9 @@ def test_bench_prints_one_json_line(form):
         two = d["two_sweep"]                # the reference's formulation, timed in the same process
         assert two["kernel"] == "sweep_pipe_kernel" and two["steps"] == 10 and two["frac"] > 0
         assert abs(two["frac"] - two["achieved"] / two["peak"]) < 1e-12
+    if form == "triple":                    # the default on one GPU: three steps per launch, the double step beside it
+        assert rf["kernel"] == "ring_step_kernel" and "note" in rf
+        assert d["double_step"]["kernel"] == "fused2_step_kernel" and d["double_step"]["frac"] > 0
 
 
 @pytest.mark.parametrize("driver", ["auto", "torch"])
@@ -108,7 +111,7 @@ def test_bench_strong_scaling_cuts_one_lattice_into_slabs():
     assert d["self_check"]["ok"] is True and d["driver_ran"] == "c"
 
 
-@pytest.mark.parametrize("gpus,steps,warmup", [(1, 7, 1), (2, 5, 3), (2, 1, 0)])
+@pytest.mark.parametrize("gpus,steps,warmup", [(1, 7, 1), (1, 8, 3), (1, 2, 0), (2, 5, 3), (2, 1, 0)])
 def test_bench_takes_odd_step_counts(gpus, steps, warmup):
     """Whatever --steps and --warmup the caller picks: an odd count ends on a single step."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", str(steps),

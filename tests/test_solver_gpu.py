@@ -89,14 +89,20 @@ def test_program_output_forms(solver_bin, oracle, tmp_path):
     assert bad.returncode != 0 and 'ERROR: Faled to open file "no_such_dir/x.txt" for writing.' in bad.stderr
 
 
-@pytest.mark.parametrize("tmax", ["0.012", "0.011"])     # averaging starts on the first / the second of a pair
-@pytest.mark.parametrize("env", [None, {"SLB_FORM": "fused"}, {"SLB_AV": "chain"}])
+@pytest.mark.parametrize("tmax", ["0.012", "0.011", "0.013"])     # averaging starts on the first / second / third iteration of a launch
+@pytest.mark.parametrize("env", [None, {"SLB_FORM": "fused"}, {"SLB_AV": "chain"}, {"SLB_STEPS_PER_LAUNCH": "3"},
+                                 {"SLB_STEPS_PER_LAUNCH": "3", "SLB_AV": "tree"}])
 def test_program_display4_wide_lattice_parallel_exact_sums(solver_bin, oracle, tmp_path, env, tmax):
     """display=4 on a lattice wide enough for the parallel form of the exact sums, fed from the
     rows the double-step kernel hands out and summed on the side streams: the record still
     equals the oracle's to the last digit."""
     args = ["display=4", "omega=100", "B=0.1", "n-harmonics=8", "g-grid=70001", "t-max=" + tmax] + COMMON
     gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args, env=env)
+    if env and env.get("SLB_AV") == "tree":          # (three iterations per launch with the tree sums: the noisy columns aside)
+        a, b = (gdir / "out.txt").read_text().splitlines(), (odir / "out.txt").read_text().splitlines()
+        ca, cb = a[2].split(), b[2].split()
+        assert a[:2] == b[:2] and [ca[i] for i in (0, 1, 2, 3, 4, 6, 7, 8)] == [cb[i] for i in (0, 1, 2, 3, 4, 6, 7, 8)]
+        return
     assert (gdir / "out.txt").read_text() == (odir / "out.txt").read_text()
 
 
@@ -154,17 +160,23 @@ def test_program_display4_config3_shape_averaged_throughout(solver_bin, oracle, 
     oracle's to the last digit (reference: src/boltzmann_c_solver.c:164-194, 236-268, 413-437).
     The oracle runs the same lattice on the host's cores (about 25 s on 16 threads)."""
     args = ["display=4", "omega=100", "B=0.0038", "n-harmonics=128", "g-grid=1048576", "t-max=0.001"] + COMMON
-    gdir, odir = tmp_path / "gpu", tmp_path / "orc"
-    gdir.mkdir(), odir.mkdir()
-    g = subprocess.run([solver_bin] + args + ["o=out.txt"], cwd=gdir, capture_output=True, text=True, timeout=600,
-                       env={**os.environ, "SLB_TIMING": "1"})
-    assert g.returncode == 0, g.stdout + g.stderr
-    assert "64 iterations" in g.stderr, g.stderr
+    odir = tmp_path / "orc"
+    odir.mkdir()
     threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or 16
     oracle.run_cli(args + ["o=out.txt"], cwd=odir, threads=threads, timeout=900)
-    got, exp = (gdir / "out.txt").read_text(), (odir / "out.txt").read_text()
+    exp = (odir / "out.txt").read_text()
     assert len(exp.splitlines()) == 3
-    assert got == exp
+    # the default on this lattice: three iterations per launch (the LDS-ring kernel handing out the rows
+    # of all three); then two per launch
+    for form in ("", "double"):
+        gdir = tmp_path / ("gpu" + form)
+        gdir.mkdir()
+        g = subprocess.run([solver_bin] + args + ["o=out.txt"], cwd=gdir, capture_output=True, text=True, timeout=600,
+                           env={**os.environ, "SLB_TIMING": "1", "SLB_FORM": form, "SLB_SHOW_SCHEDULE": "1"})
+        assert g.returncode == 0, g.stdout + g.stderr
+        assert "64 iterations" in g.stderr, g.stderr
+        assert ("slb schedule: S=3" in g.stderr) == (form == ""), g.stderr
+        assert (gdir / "out.txt").read_text() == exp, form
 
 
 def test_program_display8_identical(solver_bin, oracle, tmp_path):
@@ -354,7 +366,7 @@ def test_double_step_bit_exact(slb, oracle, N, M, B, omega, pairs, n_chunk):
 
 @pytest.mark.parametrize("S,variant", [(1, 0), (2, 0), (3, 0), (4, 0), (2, 34), (3, 32), (3, 33), (4, 32), (2, 35), (2, 37), (3, 36), (4, 35), (4, 36),
                                        (2, 70), (2, 73), (3, 71), (3, 72), (3, 73), (3, 74), (3, 75),
-                                       (2, 80), (2, 82), (2, 84), (3, 80), (3, 81), (3, 83), (2, 90), (2, 91), (3, 90)])
+                                       (2, 80), (2, 82), (2, 84), (3, 80), (3, 81), (3, 83), (2, 90), (2, 91), (3, 90), (3, 1)])
 @pytest.mark.parametrize("N,M,B,omega,n_chunk", [
     (1, 5, 0.5, 3.0, 0), (2, 61, 0.05, 100.0, 0), (5, 61, 0.05, 100.0, 2), (7, 300, 0.4, 10.0, 3),
     (32, 4096, 1.0, 1.0, 0), (33, 1000, 0.5, 30.0, 5), (16, 239, 0.3, 10.0, 0), (16, 240, 0.3, 10.0, 8),
@@ -435,6 +447,60 @@ def test_double_step_hands_out_the_rows_av_reads(slb, oracle, N, M, B, omega):
         assert np.array_equal(av_dev.cpu().numpy().view(np.uint32), av_cpu.view(np.uint32))
         _compare_live_state(sol, orc, M)
     finally:
+        sol.close()
+        orc.close()
+
+
+@pytest.mark.parametrize("S", [1, 2, 3])
+@pytest.mark.parametrize("N,M,B,omega,n_chunk", [(1, 5, 0.5, 3.0, 0), (2, 61, 0.05, 100.0, 0), (8, 61, 0.05, 100.0, 3),
+                                                 (32, 4096, 1.0, 1.0, 0), (64, 40001, 0.1, 10.0, 0),
+                                                 (64, 40001, 0.1, 10.0, 1), (33, 70001, 0.1, 10.0, 7)])
+def test_multi_step_hands_out_the_rows_av_reads(slb, oracle, S, N, M, B, omega, n_chunk):
+    """slb_step_multi_rows (S = 3: the LDS-ring kernel): the side buffers hold a rows 0, 1 and b
+    row 1 of the main lattice after EACH of the S iterations (the ones in between are stored
+    nowhere else), bit for bit; the exact sums formed from them are the oracle's av() of those
+    lattices; the lattices afterwards are the oracle's."""
+    import ctypes as C
+    import torch
+    p = oracle.make_params(N=N, M=M, B=B, omega=omega)
+    slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    orc = oracle.OracleState(p)
+    sol = slb.Solver()
+    L = slb.lib()
+    try:
+        sol.tiptoe()
+        sol.multi_step(S)
+        sol.step_fused()
+        orc.step(S + 1)
+        L.slb_set_tuning(0, n_chunk, 0)
+        pitch = sol.s.pitch
+        rows = [torch.full((3, pitch), 7.0, dtype=torch.float32, device="cuda") for _ in range(S)]
+        av_dev = torch.zeros(6, dtype=torch.float32, device="cuda")
+        tot = [torch.zeros(4, dtype=torch.float32, device="cuda") for _ in range(S)]
+        av_cpu = np.zeros(6, np.float32)
+        sol.multi_step_rows(S, [r.data_ptr() for r in rows])
+        slab = slb.Slab(pitch, 0, 1, M)
+        a_ptrs = (C.c_void_p * S)(*[r.data_ptr() for r in rows])
+        b_ptrs = (C.c_void_p * S)(*[r.data_ptr() + 4 * pitch for r in rows])
+        t_ptrs = (C.c_void_p * S)(*[t.data_ptr() for t in tot])
+        assert L.slb_av_sums_exact_n(C.byref(slab), S, a_ptrs, b_ptrs, t_ptrs) == 0
+        for k in range(S):
+            t_k = np.float32(orc.st.t)
+            orc.step(1)
+            cur = orc.st.current
+            a, b = orc.array("a", cur), orc.array("b", cur)
+            got = rows[k].cpu().numpy()
+            for r, exp in ((0, a[0]), (1, a[1]), (2, b[1])):
+                assert np.array_equal(got[r, 1:M + 2].view(np.uint32), exp[1:M + 2].view(np.uint32)), (k, r)
+            oracle.lib().orc_av(C.byref(p), a, b, av_cpu, t_k)
+            assert L.slb_av_update_exact(tot[k].data_ptr(), av_dev.data_ptr(), t_k) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(av_dev.cpu().numpy().view(np.uint32), av_cpu.view(np.uint32))
+        _compare_live_state(sol, orc, M)
+        assert sol.s.t == orc.st.t
+    finally:
+        L.slb_set_tuning(0, 0, 0)
         sol.close()
         orc.close()
 
