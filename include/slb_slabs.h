@@ -12,7 +12,7 @@
  * A run:   rank 0: slb_link_unique_id(id) and hands id to the others (any channel);
  *          every rank, its GPU current: link = slb_link_open_rccl(rank, nranks, id);
  *          run = slb_slabs_create(rank, nranks, link); slb_slabs_tiptoe(run);
- *          slb_slabs_double_step(run, NULL, NULL) ...; slb_slabs_last_step(run);
+ *          slb_slabs_multi_step(run, 3, NULL) ...; slb_slabs_last_step(run);
  *          slb_slabs_gather_rows(...) on every rank (rank 0 receives);
  *          slb_slabs_destroy(run); slb_link_close(link).
  * Every rank makes the same calls in the same order: messages are matched by order.
@@ -58,12 +58,15 @@ void       *slb_slabs_main_stream(slb_slabs *r);
 int         slb_slabs_ranks_seen(slb_slabs *r);
 void        slb_slabs_tiptoe(slb_slabs *r);
 void        slb_slabs_double_step(slb_slabs *r, float *rows_first, float *rows_second);
+/* S = 2 or 3 iterations per launch (3: the form a wide slab runs fastest); rows: NULL, or S
+ * [3][pitch] device buffers for the rows av() reads of the S new main lattices */
+void        slb_slabs_multi_step(slb_slabs *r, int S, float *const *rows);
 void        slb_slabs_step(slb_slabs *r);          /* one iteration, ghost columns refreshed */
 void        slb_slabs_last_step(slb_slabs *r);     /* the last iteration of a run: nothing travels */
 void        slb_slabs_join(slb_slabs *r);
 /* av() over slabs, bit-identical to the single-GPU av(): buffers for the next step's rows,
  * the step's loop times once it has been queued, and the end of the chain (av6 on rank 0) */
-void        slb_slabs_av_rows(slb_slabs *r, int n, float *rows[2]);
+void        slb_slabs_av_rows(slb_slabs *r, int n, float *rows[]);    /* n = 1..3 */
 void        slb_slabs_av_submit(slb_slabs *r, int n, const float *t, int skip);
 void        slb_slabs_av_submit_current(slb_slabs *r, float t);
 void        slb_slabs_av_finish(slb_slabs *r, float av6[6]);

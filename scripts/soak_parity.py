@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Long full-lattice parity run at the headline shape: n-harmonics=128, g-grid=2^20, `--steps`
-loop iterations taken as double steps on the GPU and as single steps by the CPU oracle (OpenMP),
-then every cell of the current lattices compared bit for bit, and av() of the final lattice.
+loop iterations taken on the GPU the way the program takes them (--form auto: three per launch on a
+lattice this wide, a remainder as a double and a single step; --form double: two per launch) and as
+single steps by the CPU oracle (OpenMP), then every cell of the current lattices compared bit for
+bit, and av() of the final lattice.
 A one-off check (about a minute of CPU per 100 steps), not part of the test suite."""
 import argparse
 import ctypes as C
@@ -23,6 +25,7 @@ def main():
     ap.add_argument("--n-harmonics", type=int, default=128)
     ap.add_argument("--g-grid", type=int, default=1 << 20)
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--form", choices=("auto", "double"), default="auto")
     args = ap.parse_args()
     import torch
     import oracle_binding as ob
@@ -35,12 +38,16 @@ def main():
     sol = slb.Solver()
     sol.tiptoe()
     t0 = time.perf_counter()
-    for _ in range(args.steps // 2):
-        sol.double_step()
-    if args.steps % 2:
-        sol.step_fused()
+    per_launch = sol.steps_per_launch() if args.form == "auto" else 2
+    left, launches = args.steps, {3: 0, 2: 0, 1: 0}
+    while left > 0:
+        k = per_launch if left >= per_launch else (2 if left >= 2 else 1)
+        {3: lambda: sol.multi_step(3), 2: sol.double_step, 1: sol.step_fused}[k]()
+        launches[k] += 1
+        left -= k
     torch.cuda.synchronize()
-    print(f"GPU: {args.steps} iterations in {time.perf_counter() - t0:.3f} s", flush=True)
+    print(f"GPU: {args.steps} iterations in {time.perf_counter() - t0:.3f} s "
+          f"({launches[3]} launches of three, {launches[2]} of two, {launches[1]} of one)", flush=True)
     orc = ob.OracleState(p, threads=args.threads)
     t0 = time.perf_counter()
     done = 0

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense what scripts/profile_r02.sh left under gpurun_out/<dir> into profiles/<round>/:
+"""Condense what scripts/profile_r03.sh (or profile_r02.sh) left under gpurun_out/<dir> into profiles/<round>/:
 per run the kernel's rocprofv3 statistics (calls, average / min / max duration), the HBM bytes
 per launch from the FETCH_SIZE and WRITE_SIZE passes (KiB units; FETCH_SIZE doubled: on gfx950
 it tallies 128-byte requests of wide coalesced reads at 64 bytes), the bench line printed
@@ -12,7 +12,7 @@ import os
 import shutil
 import sys
 
-KERNEL = {"double": "fused2_step_kernel", "fused": "fused_step_kernel", "sweeps": "sweep_pipe_kernel"}
+KERNEL = {"triple": "ring_step_kernel", "double": "fused2_step_kernel", "fused": "fused_step_kernel", "sweeps": "sweep_pipe_kernel"}
 
 
 def counter(dirname, name, kernel):
@@ -30,7 +30,7 @@ def main():
     os.makedirs(dst, exist_ok=True)
     traffic = {"_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; "
                         "FETCH_SIZE doubled per the gfx950 note; KiB units) of `python3 bench.py --no-cpu "
-                        "--no-two-sweep --repeats 1 ...`; scripts/profile_r02.sh, scripts/summarise_profiles.py"}
+                        "--no-two-sweep --repeats 1 ...`; scripts/profile_r03.sh (profile_r02.sh in round 2), scripts/summarise_profiles.py"}
     summary = {}
     for log in sorted(glob.glob(os.path.join(src, "trace_*.log"))):
         tag = os.path.basename(log)[len("trace_"):-len(".log")]

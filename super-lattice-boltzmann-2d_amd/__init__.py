@@ -227,6 +227,11 @@ def lib():
         L.slb_slabs_ranks_seen.argtypes, L.slb_slabs_ranks_seen.restype = [vp], i
         L.slb_slabs_tiptoe.argtypes, L.slb_slabs_tiptoe.restype = [vp], None
         L.slb_slabs_double_step.argtypes, L.slb_slabs_double_step.restype = [vp, fp, fp], None
+        L.slb_slabs_multi_step.argtypes, L.slb_slabs_multi_step.restype = [vp, i, C.POINTER(C.c_void_p)], None
+        L.slb_solver_halo_pack_multi.argtypes = [C.POINTER(SolverStruct), i, fp, fp]
+        L.slb_solver_halo_pack_multi.restype = i
+        L.slb_solver_halo_unpack_multi.argtypes = [C.POINTER(SolverStruct), i, fp, fp]
+        L.slb_solver_halo_unpack_multi.restype = i
         L.slb_slabs_last_step.argtypes, L.slb_slabs_last_step.restype = [vp], None
         L.slb_slabs_step.argtypes, L.slb_slabs_step.restype = [vp], None
         L.slb_link_rank.argtypes, L.slb_link_rank.restype = [vp], i
@@ -238,7 +243,7 @@ def lib():
         L.slb_slabs_av_data.argtypes, L.slb_slabs_av_data.restype = [vp], vp
         L.slb_slabs_write_frame.argtypes, L.slb_slabs_write_frame.restype = [vp, C.c_char_p, f], i
         L.slb_slabs_join.argtypes, L.slb_slabs_join.restype = [vp], None
-        L.slb_slabs_av_rows.argtypes, L.slb_slabs_av_rows.restype = [vp, i, C.POINTER(C.c_void_p * 2)], None
+        L.slb_slabs_av_rows.argtypes, L.slb_slabs_av_rows.restype = [vp, i, C.POINTER(C.c_void_p)], None
         L.slb_slabs_av_submit.argtypes, L.slb_slabs_av_submit.restype = [vp, i, C.POINTER(C.c_float), i], None
         L.slb_slabs_av_submit_current.argtypes, L.slb_slabs_av_submit_current.restype = [vp, f], None
         L.slb_slabs_av_finish.argtypes, L.slb_slabs_av_finish.restype = [vp, C.POINTER(C.c_float * 6)], None

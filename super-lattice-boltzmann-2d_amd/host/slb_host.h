@@ -167,6 +167,12 @@ int slb_solver_copy_av_rows(slb_solver *s, float *rows);
  * into the spare arrays); NULL for a side without a neighbour */
 int slb_solver_halo_pack_double  (slb_solver *s, float *buf_left, float *buf_right);
 int slb_solver_halo_unpack_double(slb_solver *s, float *buf_left, float *buf_right);
+/* the same for a launch of S = 1..3 steps, between its edge ranges and
+ * slb_solver_multi_step_finish(): 2S-1 main-lattice columns, then 2S half-step columns, per
+ * neighbour 2*(4S-1)*(N+1) floats; the new lattices are in the spare arrays for S = 2, in
+ * a/b[next] and a/b[next_hs] for odd S */
+int slb_solver_halo_pack_multi  (slb_solver *s, int S, float *buf_left, float *buf_right);
+int slb_solver_halo_unpack_multi(slb_solver *s, int S, float *buf_left, float *buf_right);
 
 /* frame values (device sums, host libm factors) of the slab's main-lattice columns for
  * nphi values of phi_x; out = nphi x (main_slab.j_last-j_first+1) floats on the host.

@@ -5,15 +5,15 @@
  * The reference runs on one GPU; the loop this spreads over several is
  * reference src/boltzmann_solver.c:196-302, its display=4 record :348-380.
  *
- * Per double step (two loop iterations per launch, slb_step_fused2) and slab:
+ * Per launch of S = 2 or 3 loop iterations (slb_step_fused2, slb_step_multi) and slab:
  *
- *   side stream:  edge column ranges -> pack -> { send/recv 7 columns per neighbour,
+ *   side stream:  edge column ranges -> pack -> { send/recv 4S-1 columns per neighbour,
  *                 + totals of av() on their way down the chain } -> unpack
  *   main stream:  interior column range
  *
- * Each stream waits for the other's PREVIOUS double step only (results go to the spare
- * arrays), so interior launches follow each other without a gap and the few-KB messages
- * travel meanwhile.  Lattices are bit-identical to a single-GPU run.
+ * Each stream waits for the other's PREVIOUS launch only (results go to arrays the present
+ * lattices are not in), so interior launches follow each other without a gap and the few-KB
+ * messages travel meanwhile.  Lattices are bit-identical to a single-GPU run.
  *
  * av() over slabs: the reference's three sums are ONE float running sum over all columns
  * (reference: src/boltzmann_c_solver.c:413-437), so slab r starts from the totals slab r-1
@@ -41,7 +41,7 @@
 
 #define HIP_OK(call) HandleError((int)(call), __FILE__, __LINE__)
 
-#define AVC_BATCH 4                 /* double steps per launch of the sums (8 lattices)           */
+#define AVC_BATCH 4                 /* launches of the time loop per launch of the sums at most     */
 #define AVC_LAG   4                 /* exchanges between a batch's arrival on a rank and its leaving */
 #define AVC_SETS  8                 /* lattices per batch at most                                  */
 
@@ -63,8 +63,8 @@ struct slb_slabs {
   hipStream_t main, side, av;
   hipEvent_t  ev_main, ev_side, ev_x;
   int   side_busy;
-  float *send2[2], *recv2[2];       /* a double step's message per side: 2*7*(N+1) floats          */
-  float *send4[2], *recv4[2];       /* 4 columns of one lattice: 2*4*(N+1) floats                  */
+  float *send2[2], *recv2[2];       /* a launch's message per side: up to 2*11*(N+1) floats         */
+  float *send4[2], *recv4[2];       /* G columns of one lattice: 2*G*(N+1) floats                  */
   long  exchanges;                  /* message groups so far (the clock of the av schedule)        */
   /* av chain */
   av_batch *ring;                   /* ring of batches                                             */
@@ -189,16 +189,16 @@ static slb_slabs *slabs_create(int rank, int nranks, slb_link *link, int loopbac
   HIP_OK(hipEventCreateWithFlags(&r->ev_x, hipEventDisableTiming));
   const size_t col = sizeof(float) * 2 * (size_t)(r->s->N + 1);
   for (int side = 0; side < 2; side++) {
-    HIP_OK(hipMalloc((void **)&r->send2[side], 7 * col));
-    HIP_OK(hipMalloc((void **)&r->recv2[side], 7 * col));
-    HIP_OK(hipMalloc((void **)&r->send4[side], 4 * col));
-    HIP_OK(hipMalloc((void **)&r->recv4[side], 4 * col));
+    HIP_OK(hipMalloc((void **)&r->send2[side], 11 * col));
+    HIP_OK(hipMalloc((void **)&r->recv2[side], 11 * col));
+    HIP_OK(hipMalloc((void **)&r->send4[side], 6 * col));
+    HIP_OK(hipMalloc((void **)&r->recv4[side], 6 * col));
   }
   HIP_OK(hipMalloc((void **)&r->av_data, 6 * sizeof(float)));
   HIP_OK(hipMemset(r->av_data, 0, 6 * sizeof(float)));
   /* batches alive at once: one being filled, AVC_LAG exchanges per rank upstream on their
    * way here, one being summed, one waiting to leave */
-  r->ring_n = AVC_LAG * nranks / AVC_BATCH + 4;
+  r->ring_n = AVC_LAG * nranks / 2 + 4;                 /* (a batch is complete after two launches of three steps) */
   r->ring = (av_batch *)calloc((size_t)r->ring_n, sizeof(av_batch));
   for (int k = 0; k < r->ring_n; k++) {
     r->ring[k].ready = -1;
@@ -277,12 +277,69 @@ void slb_slabs_tiptoe(slb_slabs *r)
   on_stream(r->side);
   slb_solver_tiptoe(r->s);
   for (int side = 0; side < 2; side++)
-    if ((side == 0 ? r->left : r->right) >= 0) check(slb_solver_halo_pack(r->s, 0, side, 4, r->send4[side]), "halo pack");
-  exchange(r, r->send4, r->recv4, 2 * 4 * (size_t)(r->s->N + 1));
+    if ((side == 0 ? r->left : r->right) >= 0) check(slb_solver_halo_pack(r->s, 0, side, r->s->G, r->send4[side]), "halo pack");
+  exchange(r, r->send4, r->recv4, 2 * (size_t)r->s->G * (size_t)(r->s->N + 1));
   for (int side = 0; side < 2; side++)
-    if ((side == 0 ? r->left : r->right) >= 0) check(slb_solver_halo_unpack(r->s, 0, side, 4, r->recv4[side]), "halo unpack");
+    if ((side == 0 ? r->left : r->right) >= 0) check(slb_solver_halo_unpack(r->s, 0, side, r->s->G, r->recv4[side]), "halo unpack");
   HIP_OK(hipStreamSynchronize(r->side));
   on_stream(r->main);
+}
+
+/* S = 2 or 3 loop iterations in one launch per column range.  rows (NULL or S pointers): [3][pitch]
+ * device buffers that receive the rows av() reads of the main lattice after each of the S
+ * iterations, at this slab's columns. */
+void slb_slabs_multi_step(slb_slabs *r, int S, float *const *rows)
+{
+  slb_solver *s = r->s;
+  if (S != 2 && S != 3) { fprintf(stderr, "ERROR: slb_slabs_multi_step takes 2 or 3 steps per launch\n"); exit(EXIT_FAILURE); }
+  const int Q = 2 * S, even = S == 2;
+  float c[16];
+  MARK(r, S == 2 ? "slb_slabs_multi_step (2)" : "slb_slabs_multi_step (3)");
+  r->double_steps++;
+  slb_steps_cosines(s->t, S, c);
+  /* a neighbour needs this slab's outermost 2S-1 main and 2S half-step columns: the edge ranges are
+   * the 2S outermost owned columns of the last sweep, the interior the rest */
+  const int first = s->G, last_owned = s->G + s->W - 1;
+  const int lo = r->left >= 0 ? first + Q : first;
+  const int hi = r->right >= 0 ? last_owned - Q : last_owned;
+  if (r->nranks == 1) {
+    on_stream(r->main);
+    slb_solver_multi_step_range_rows(s, S, lo, hi, c, rows);
+    HIP_OK(hipEventRecord(r->ev_main, r->main));
+    exchange(r, NULL, NULL, 0);                       /* the clock of the av schedule ticks all the same */
+    slb_solver_multi_step_finish(s, S);
+    return;
+  }
+  on_stream(r->main);
+  /* two steps write the spare arrays: if stale (first use, or an odd number of steps since) they are
+   * copied on the main stream, after whatever the side stream still has to put into the lattices
+   * they are copies of.  Three steps write a/b[next], a/b[next_hs], which hold no lattice in use. */
+  const int stale = even && (!s->spare_a || s->spare_of != s->current || s->spare_of_hs != s->current_hs);
+  if (r->side_busy && stale) HIP_OK(hipStreamWaitEvent(r->main, r->ev_side, 0));
+  if (even) slb_solver_prepare_double_step(s);
+  /* halo chain: reads what the last interior launch wrote, writes the output arrays' edge and
+   * ghost columns (which that launch read, when they were its inputs).  When the spares were
+   * just re-copied on the main stream the event has to stand behind those copies: the side
+   * stream's edge launches and halo unpack write the same arrays. */
+  if (!r->side_busy || stale) HIP_OK(hipEventRecord(r->ev_main, r->main));
+  HIP_OK(hipStreamWaitEvent(r->side, r->ev_main, 0));
+  on_stream(r->side);
+  if (r->left >= 0)  slb_solver_multi_step_range_rows(s, S, first, first + Q - 1, c, rows);
+  if (r->right >= 0) slb_solver_multi_step_range_rows(s, S, last_owned - (Q - 1), last_owned, c, rows);
+  check(slb_solver_halo_pack_multi(s, S, r->left >= 0 ? r->send2[0] : NULL, r->right >= 0 ? r->send2[1] : NULL), "halo pack");
+  exchange(r, r->send2, r->recv2, 2 * (size_t)(2 * Q - 1) * (size_t)(s->N + 1));
+  /* interior: reads what the last halo chain wrote, writes the output arrays' interior
+   * (which that chain read) */
+  if (r->side_busy) HIP_OK(hipStreamWaitEvent(r->main, r->ev_side, 0));
+  on_stream(r->main);
+  slb_solver_multi_step_range_rows(s, S, lo, hi, c, rows);
+  HIP_OK(hipEventRecord(r->ev_main, r->main));
+  on_stream(r->side);
+  check(slb_solver_halo_unpack_multi(s, S, r->left >= 0 ? r->recv2[0] : NULL, r->right >= 0 ? r->recv2[1] : NULL), "halo unpack");
+  HIP_OK(hipEventRecord(r->ev_side, r->side));
+  r->side_busy = 1;
+  on_stream(r->main);
+  slb_solver_multi_step_finish(s, S);                 /* the output arrays become the current lattices */
 }
 
 /* Two loop iterations.  rows_first / rows_second (both or neither): [3][pitch] device
@@ -290,51 +347,8 @@ void slb_slabs_tiptoe(slb_slabs *r)
  * the second iteration, at this slab's columns. */
 void slb_slabs_double_step(slb_slabs *r, float *rows_first, float *rows_second)
 {
-  slb_solver *s = r->s;
-  float c[8];
-  MARK(r, "slb_slabs_double_step");
-  r->double_steps++;
-  slb_step2_cosines(s->t, c);
-  const int first = s->G, last_owned = s->G + s->W - 1;
-  const int lo = r->left >= 0 ? first + 4 : first;
-  const int hi = r->right >= 0 ? last_owned - 4 : last_owned;
-  if (r->nranks == 1) {
-    on_stream(r->main);
-    slb_solver_double_step_range_rows(s, lo, hi, c, rows_first, rows_second);
-    HIP_OK(hipEventRecord(r->ev_main, r->main));
-    exchange(r, NULL, NULL, 0);                       /* the clock of the av schedule ticks all the same */
-    slb_solver_double_step_finish(s);
-    return;
-  }
-  on_stream(r->main);
-  /* spare arrays, if stale (first use, or a single step since): copied on the main stream,
-   * after whatever the side stream still has to put into the lattices they are copies of */
-  const int stale = !s->spare_a || s->spare_of != s->current || s->spare_of_hs != s->current_hs;
-  if (r->side_busy && stale) HIP_OK(hipStreamWaitEvent(r->main, r->ev_side, 0));
-  slb_solver_prepare_double_step(s);
-  /* halo chain: reads what the last interior launch wrote, writes the spare arrays' edge
-   * and ghost columns (which that launch read).  When the spares were just re-copied on the
-   * main stream the event has to stand behind those copies: the side stream's edge launches
-   * and halo unpack write the same arrays. */
-  if (!r->side_busy || stale) HIP_OK(hipEventRecord(r->ev_main, r->main));
-  HIP_OK(hipStreamWaitEvent(r->side, r->ev_main, 0));
-  on_stream(r->side);
-  if (r->left >= 0)  slb_solver_double_step_range_rows(s, first, first + 3, c, rows_first, rows_second);
-  if (r->right >= 0) slb_solver_double_step_range_rows(s, last_owned - 3, last_owned, c, rows_first, rows_second);
-  check(slb_solver_halo_pack_double(s, r->left >= 0 ? r->send2[0] : NULL, r->right >= 0 ? r->send2[1] : NULL), "halo pack");
-  exchange(r, r->send2, r->recv2, 2 * 7 * (size_t)(s->N + 1));
-  /* interior: reads what the last halo chain wrote, writes the spare arrays' interior
-   * (which that chain read) */
-  if (r->side_busy) HIP_OK(hipStreamWaitEvent(r->main, r->ev_side, 0));
-  on_stream(r->main);
-  slb_solver_double_step_range_rows(s, lo, hi, c, rows_first, rows_second);
-  HIP_OK(hipEventRecord(r->ev_main, r->main));
-  on_stream(r->side);
-  check(slb_solver_halo_unpack_double(s, r->left >= 0 ? r->recv2[0] : NULL, r->right >= 0 ? r->recv2[1] : NULL), "halo unpack");
-  HIP_OK(hipEventRecord(r->ev_side, r->side));
-  r->side_busy = 1;
-  on_stream(r->main);
-  slb_solver_double_step_finish(s);                   /* the spares become the current lattices */
+  float *rows[2] = {rows_first, rows_second};
+  slb_slabs_multi_step(r, 2, rows_first && rows_second ? rows : NULL);
 }
 
 /* the main stream waits for the side stream's halo work (before anything but another
@@ -362,8 +376,8 @@ void slb_slabs_last_step(slb_slabs *r)
 
 /* One loop iteration as one fused launch, after which any step may follow: the slab forms
  * both sweeps for all its columns (as above), then the ghost columns of both new lattices
- * come from the neighbours -- 3 columns of the main lattice, 4 of the half-step one, the
- * depth a double step reads. */
+ * come from the neighbours -- G-1 columns of the main lattice, G of the half-step one, the
+ * depth a launch of three steps reads. */
 void slb_slabs_step(slb_slabs *r)
 {
   slb_solver *s = r->s;
@@ -374,7 +388,7 @@ void slb_slabs_step(slb_slabs *r)
   HIP_OK(hipEventRecord(r->ev_main, r->main));
   HIP_OK(hipStreamWaitEvent(r->side, r->ev_main, 0));
   on_stream(r->side);
-  static const int which[2] = {3, 0}, ncols[2] = {3, 4};    /* current main lattice, current half-step lattice */
+  const int which[2] = {3, 0}, ncols[2] = {s->G - 1, s->G};  /* current main lattice, current half-step lattice */
   for (int k = 0; k < 2; k++) {
     for (int side = 0; side < 2; side++)
       if ((side == 0 ? r->left : r->right) >= 0)
@@ -409,9 +423,9 @@ static void batch_reset(slb_slabs *r, av_batch *b)
   b->n = 0; b->steps = 0; b->ready = -1; b->summed = 0; b->sent = 0;
 }
 
-/* Row buffers for the next one or two lattices to average (the next double step's, or the
+/* Row buffers for the next one to three lattices to average (the next launch's, or the
  * last single step's): rows[0..n-1]. */
-void slb_slabs_av_rows(slb_slabs *r, int n, float *rows[2])
+void slb_slabs_av_rows(slb_slabs *r, int n, float *rows[])
 {
   av_batch *b = batch_at(r, r->batch_open);
   if (b->ready >= 0 || !b->init) {
@@ -465,25 +479,28 @@ static void batch_close(slb_slabs *r)
   if (r->left < 0) av_launch_ready(r);
 }
 
-/* The step that fills the buffers handed out by slb_slabs_av_rows() has been queued: n
- * lattices at loop times t[0..n-1], buffers rows[skip .. skip+n-1] of that call (skip = 1:
- * only the second iteration of a double step is averaged). */
+/* The launch that fills the buffers handed out by slb_slabs_av_rows() has been queued: n
+ * lattices at loop times t[0..n-1], buffers rows[skip .. skip+n-1] of that call (skip > 0:
+ * the first `skip` iterations of the launch are not averaged). */
 void slb_slabs_av_submit(slb_slabs *r, int n, const float *t, int skip)
 {
   av_batch *b = batch_at(r, r->batch_open);
-  if (skip) {                                  /* the lattice to average sits in the second buffer */
-    float *x = b->rows[b->n]; b->rows[b->n] = b->rows[b->n + 1]; b->rows[b->n + 1] = x;
+  if (skip) {                                  /* the lattices to average sit behind `skip` others: bring them forward */
+    float *x[AVC_SETS];
+    for (int k = 0; k < skip + n; k++) x[k] = b->rows[b->n + k];
+    for (int k = 0; k < n; k++) b->rows[b->n + k] = x[skip + k];
+    for (int k = 0; k < skip; k++) b->rows[b->n + n + k] = x[k];
   }
   for (int k = 0; k < n; k++) b->t[b->n + k] = t[k];
   b->n += n;
   b->steps++;
-  if (b->steps >= AVC_BATCH || b->n + 2 > AVC_SETS) batch_close(r);
+  if (b->steps >= AVC_BATCH || b->n + 3 > AVC_SETS) batch_close(r);     /* room for a launch of three */
 }
 
 /* the three rows of the current main lattice -> the next row buffer, then as above */
 void slb_slabs_av_submit_current(slb_slabs *r, float t)
 {
-  float *rows[2];
+  float *rows[3];
   slb_slabs_av_rows(r, 1, rows);
   slb_slabs_join(r);
   check(slb_solver_copy_av_rows(r->s, rows[0]), "copying the rows of av()");
@@ -810,6 +827,8 @@ static int rank_main(int rank, int nranks, const int *fds)
   }
 
   const int timing = getenv("SLB_TIMING") != NULL;
+  const char *form = getenv("SLB_FORM");
+  const int triples = !(form != NULL && strcmp(form, "double") == 0) && slb_solver_steps_per_launch(s) == 3;
   int progress = 0, frame_number = 1;
   float t = 0, t0 = 0, frame_time = 0, last_phase = 0;
   char file_name[64];
@@ -824,7 +843,31 @@ static int rank_main(int rank, int nranks, const int *fds)
       const int k1 = step_kind(t, frame_time);
       const float t2 = t + host_dt, ft2 = frame_time + host_dt;
       const int k2 = step_kind(t2, ft2);
+      const float t3 = t2 + host_dt, ft3 = ft2 + host_dt;
+      const int k3 = step_kind(t3, ft3);
       s->t = t;                              /* the engine forms the cosines from its own clock */
+      if (triples && t2 < t_max && t3 < t_max && k1 < 2 && k2 < 2 && k3 < 2) {
+        /* three iterations in one launch */
+        const int n_av = k1 + k2 + k3;
+        if (n_av) {
+          float *rows[3];
+          slb_slabs_av_rows(r, 3, rows);
+          slb_slabs_multi_step(r, 3, rows);
+          const float tk[3] = {t, t2, t3};
+          slb_slabs_av_submit(r, n_av, tk + (3 - n_av), 3 - n_av);   /* averaging, once begun, goes on */
+        } else {
+          slb_slabs_multi_step(r, 3, NULL);
+        }
+        t = t3;
+        loop_steps += 2;
+        frame_time = ft3 + host_dt;
+        if (rank == 0 && out != stdout && display != 7 && quiet == 0 && (progress += 3) >= 300) {
+          printf("\rt=%0.9f %0.2f%%", t, t / t_max * 100);
+          fflush(stdout);
+          progress = 0;
+        }
+        continue;
+      }
       if (t2 < t_max && k1 < 2 && k2 < 2) {
         /* two iterations in one launch: same bits, the lattice in between is never stored
          * (the rows av() reads of it are) */

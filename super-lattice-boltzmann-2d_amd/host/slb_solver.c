@@ -182,14 +182,14 @@ slb_solver *slb_solver_create(int rank, int nranks)
   /* columns 1..M are dealt out in contiguous runs; the last slab also carries
    * column M+1 of the main lattice and the boundary column M+2.  A slab keeps
    * G ghost columns per side: 1 for a single slab (the reference layout, the
-   * ghosts are the boundary columns 0 and M+2), 4 when there are neighbours, so
-   * that the fused steps can recompute the earlier sweeps up to three columns
-   * into the ghost zone and need one exchange per launch. */
+   * ghosts are the boundary columns 0 and M+2), 6 when there are neighbours, so
+   * that a launch of up to three steps can recompute its earlier sweeps up to five
+   * columns into the ghost zone and needs one exchange per launch. */
   const int base = host_M / nranks, rem = host_M % nranks;
   s->W = base + (rank < rem ? 1 : 0);
-  s->G = nranks == 1 ? 1 : 4;
-  if (nranks > 1 && s->W < 8) {
-    fprintf(stderr, "slb_solver_create: slabs need at least 8 columns each\n");
+  s->G = nranks == 1 ? 1 : 6;
+  if (nranks > 1 && s->W < 12) {
+    fprintf(stderr, "slb_solver_create: slabs need at least 12 columns each\n");
     free(s);
     return NULL;
   }
@@ -228,7 +228,7 @@ slb_solver *slb_solver_create(int rank, int nranks)
   HIP_OK(hipMalloc((void **)&s->av_data, 6 * sizeof(float)));
   HIP_OK(hipMemset(s->av_data, 0, 6 * sizeof(float)));
   HIP_OK(hipMalloc((void **)&s->sums, 4 * sizeof(double)));
-  HIP_OK(hipMalloc((void **)&s->halo_buf, (size_t)32 * (s->N + 1) * sizeof(float)));
+  HIP_OK(hipMalloc((void **)&s->halo_buf, (size_t)48 * (s->N + 1) * sizeof(float)));
   HIP_OK(hipDeviceSynchronize());
 
   s->current = 0; s->next = 1; s->current_hs = 2; s->next_hs = 3;
@@ -589,15 +589,17 @@ void slb_solver_multi_step_rows(slb_solver *s, int S, float *const *rows)
 }
 
 /* How many loop iterations a launch of the time loop should take on this slab: 3 where the
- * three-step kernel has the lattice to fill the device (its lanes own four columns; measured on
- * MI355X it passes the double step from about 2^19 columns at 64 harmonics up), else 2.
+ * three-step kernel has the lattice to fill the device, else 2.  Measured on MI355X (updates per
+ * second, two against three steps per launch): 2.4e11 / 2.6e11 at 64 harmonics x 2^19 columns,
+ * 2.5e11 / 3.1e11 at 128 x 2^19, 2.35e11 / 2.7e11 at 32 x 2^20, 2.6e11 / 3.9e11 at 512 x 2^20; but
+ * 2.4e11 / 2.2e11 at 128 x 2^18, 2.1e11 / 1.9e11 at 64 x 2^18 and 2.6e11 / 2.3e11 at 16 x 2^21.
  * SLB_STEPS_PER_LAUNCH=1..3 overrides. */
 int slb_solver_steps_per_launch(const slb_solver *s)
 {
   const char *e = getenv("SLB_STEPS_PER_LAUNCH");
   if (e && e[0] >= '1' && e[0] <= '3' && e[1] == 0) return e[0] - '0';
   const long waves = ((long)s->W + 239) / 240;
-  return s->N >= 48 && waves >= 2048 ? 3 : 2;
+  return s->N >= 32 && waves >= 2048 ? 3 : 2;
 }
 
 int slb_solver_run_timed(slb_solver *s, int steps, float *ms)
@@ -666,24 +668,28 @@ int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const 
  * (3 columns) and of the new half-step lattice (4 columns), both still in the spare arrays,
  * gathered for each neighbour in one launch.  A side's buffer (NULL = no neighbour there)
  * holds 2*3*(N+1) floats of the main lattice followed by 2*4*(N+1) of the half-step one. */
-static int halo_double(slb_solver *s, float *buf_left, float *buf_right, int pack)
+/* The same after the edge ranges of a launch of S steps (before slb_solver_multi_step_finish): 2S-1
+ * columns of the new main lattice, 2S of the new half-step lattice -- in the spare arrays for
+ * even S, in a/b[next] and a/b[next_hs] for odd S.  A side's buffer holds 2*(2S-1)*(N+1) floats
+ * of the main lattice followed by 2*2S*(N+1) of the half-step one. */
+static int halo_multi(slb_solver *s, int S, float *buf_left, float *buf_right, int pack)
 {
-  const int nrows = s->N + 1;
+  const int nrows = s->N + 1, Q = 2 * S, even = (S % 2) == 0;
   if (!buf_left && !buf_right) return 0;          /* a slab without neighbours */
-  if (!s->spare_a || s->G < 4) return -1;
+  if (S < 1 || S > 3 || (even && !s->spare_a) || s->G < Q) return -1;
   slb_halo_seg seg[4];
   int k = 0;
   for (int side = 0; side < 2; side++) {
     float *buf = side == 0 ? buf_left : buf_right;
     if (!buf) continue;
     for (int lat = 0; lat < 2; lat++) {
-      const int ncols = lat == 0 ? 3 : 4;
-      seg[k].a = lat == 0 ? s->spare_a : s->spare_ah;
-      seg[k].b = lat == 0 ? s->spare_b : s->spare_bh;
+      const int ncols = lat == 0 ? Q - 1 : Q;
+      seg[k].a = lat == 0 ? (even ? s->spare_a : s->a[s->next]) : (even ? s->spare_ah : s->a[s->next_hs]);
+      seg[k].b = lat == 0 ? (even ? s->spare_b : s->b[s->next]) : (even ? s->spare_bh : s->b[s->next_hs]);
       seg[k].ncols = ncols;
       if (pack) seg[k].col = side == 0 ? s->G : s->G + s->W - ncols;      /* outermost owned columns */
       else      seg[k].col = side == 0 ? s->G - ncols : s->G + s->W;      /* the ghost columns next to them */
-      seg[k].buf = buf + (lat == 0 ? 0 : 2 * 3 * nrows);
+      seg[k].buf = buf + (lat == 0 ? 0 : 2 * (Q - 1) * nrows);
       k++;
     }
   }
@@ -693,14 +699,24 @@ static int halo_double(slb_solver *s, float *buf_left, float *buf_right, int pac
   return rc;
 }
 
+int slb_solver_halo_pack_multi(slb_solver *s, int S, float *buf_left, float *buf_right)
+{
+  return halo_multi(s, S, buf_left, buf_right, 1);
+}
+
+int slb_solver_halo_unpack_multi(slb_solver *s, int S, float *buf_left, float *buf_right)
+{
+  return halo_multi(s, S, buf_left, buf_right, 0);
+}
+
 int slb_solver_halo_pack_double(slb_solver *s, float *buf_left, float *buf_right)
 {
-  return halo_double(s, buf_left, buf_right, 1);
+  return halo_multi(s, 2, buf_left, buf_right, 1);
 }
 
 int slb_solver_halo_unpack_double(slb_solver *s, float *buf_left, float *buf_right)
 {
-  return halo_double(s, buf_left, buf_right, 0);
+  return halo_multi(s, 2, buf_left, buf_right, 0);
 }
 
 /* this slab's share of the three av() sums over its own columns of the CURRENT main
