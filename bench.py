@@ -144,9 +144,8 @@ def parse_args(argv=None):
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--form", choices=("auto", "triple", "double", "fused", "sweeps"), default="auto",
                     help="triple: three steps (six sweeps) per launch, a remainder of the K steps in a "
-                         "double and a single step (default on one GPU); "
-                         "double: two steps (four sweeps) per launch (default on several GPUs: the form "
-                         "the slab driver runs); "
+                         "double and a single step (default); "
+                         "double: two steps (four sweeps) per launch; "
                          "fused: both sweeps of a step in one launch; "
                          "sweeps: the reference's two launches per step")
     ap.add_argument("--driver", choices=("auto", "c", "torch"), default="auto",
@@ -258,9 +257,10 @@ def run_single(args, slb, torch, form, steps, warmup, repeats):
 def ghost_self_check(slb, run, driver, rank, world, dist):
     """After the warm-up steps, before anything is timed: the ghost columns of both current
     lattices on every rank must be, bit for bit, the outermost columns its neighbours own --
-    they were sent through the driver's own exchange (slb_slabs_double_step: pack, RCCL
-    send/recv, unpack; 3 columns of the main lattice, 4 of the half-step lattice).  Every rank
-    learns the verdict; a mismatch ends the run non-zero naming rank, peer and lattice."""
+    they were sent through the driver's own exchange (C driver, slb_slabs_multi_step: pack, RCCL
+    send/recv, unpack, G-1 = 5 columns of the main lattice and G = 6 of the half-step lattice
+    after every launch; torch driver: 3 and 4 after a double step).  Every rank learns the
+    verdict; a mismatch ends the run non-zero naming rank, peer and lattice."""
     import numpy as np
     import torch
     run.join() if hasattr(run, "join") else None
@@ -276,7 +276,8 @@ def ghost_self_check(slb, run, driver, rank, world, dist):
             raise SystemExit(f"rank {rank}: slb_solver_get_window -> {rc}")
         return out
 
-    lattices = (("main", 1 + sol.current, 5 + sol.current, 3), ("half-step", 1 + sol.current_hs, 5 + sol.current_hs, 4))
+    d_main, d_half = (G - 1, G) if driver == "c" else (3, 4)
+    lattices = (("main", 1 + sol.current, 5 + sol.current, d_main), ("half-step", 1 + sol.current_hs, 5 + sol.current_hs, d_half))
     mine = {}
     for name, ia, ib, depth in lattices:
         for arr_name, arr in (("a", ia), ("b", ib)):
@@ -310,7 +311,7 @@ def ghost_self_check(slb, run, driver, rank, world, dist):
         dist.barrier()
         raise SystemExit(3)
     return {"ok": True, "ranks": world,
-            "checked": "ghost columns of both current lattices (3 main, 4 half-step per side, a and b, all rows) "
+            "checked": f"ghost columns of both current lattices ({d_main} main, {d_half} half-step per side, a and b, all rows) "
                        "equal the neighbours' owned edge columns bit for bit after the warm-up steps"}
 
 
@@ -335,15 +336,15 @@ def main():
     ranks_seen = 1
     driver = None
     if args.form == "auto":
-        args.form = "triple" if world == 1 else "double"
-    if world > 1 and args.form == "triple":
-        raise SystemExit("--form triple runs on one GPU (the slab driver takes two steps per launch)")
+        args.form = "double" if world > 1 and args.driver == "torch" else "triple"
     if world > 1:
         driver = args.driver
         if driver == "auto":
-            driver = "c" if args.form == "double" else "torch"
-        if driver == "c" and args.form != "double":
-            raise SystemExit("--driver c runs the double step only")
+            driver = "c" if args.form in ("double", "triple") else "torch"
+        if driver == "c" and args.form not in ("double", "triple"):
+            raise SystemExit("--driver c runs two or three steps per launch only")
+        if driver == "torch" and args.form == "triple":
+            raise SystemExit("--form triple over several GPUs is the C slab driver's (--driver c)")
         import torch.distributed as dist
         # The C driver owns the one RCCL communicator of the run (ncclCommInitRank in
         # host/slb_link.c); torch.distributed is then control plane only and runs over gloo.
@@ -390,17 +391,24 @@ def main():
 
         def advance(nsteps):
             k = 0
-            if args.form == "double":
-                for _ in range(nsteps // 2):
+            if args.form == "triple":
+                for _ in range(nsteps // 3):
+                    run.multi_step(3)
+                k = nsteps - nsteps % 3
+            if args.form in ("double", "triple"):
+                for _ in range((nsteps - k) // 2):
                     run.double_step()
-                k = nsteps - nsteps % 2
+                k += (nsteps - k) // 2 * 2
             for _ in range(nsteps - k):
                 (run.step if args.form == "sweeps" else run.step_fused)()
 
-        advance(max(args.warmup + args.warmup % 2, 2))
-        if args.no_self_check or args.form != "double":
+        if args.form == "triple":
+            advance(max((args.warmup + 2) // 3 * 3, 3))      # whole launches of three: all their ghost columns are fresh
+        else:
+            advance(max(args.warmup + args.warmup % 2, 2))
+        if args.no_self_check or args.form not in ("double", "triple"):
             self_check = {"ok": None, "skipped": "--no-self-check" if args.no_self_check else
-                          "the check knows the ghost depth of the double step only"}
+                          "the check knows the ghost depth of the multi-step launches only"}
         else:
             self_check = ghost_self_check(slb, run, driver, rank, world, dist)
         blocks = []
@@ -424,6 +432,8 @@ def main():
                 # this rank's stream time per double step: the interior launch (the edge launches
                 # and the halo traffic run beside it) plus whatever it had to wait for
                 kernel_ms = ev0.elapsed_time(ev1) / (args.steps // 2)
+            if args.form == "triple" and args.steps % 3 == 0:
+                kernel_ms = ev0.elapsed_time(ev1) / (args.steps // 3)
             w = torch.tensor([wall], dtype=torch.float64, device="cuda" if control_on_gpu else "cpu")
             dist.all_reduce(w, op=dist.ReduceOp.MAX)
             blocks.append((float(w.item()), kernel_ms))
@@ -474,7 +484,7 @@ def main():
                 traffic, source = recorded_traffic(args.form, n_harm, g_grid)
             out["roofline"] = roofline(args.form, n_harm, g_grid / world, kernel_ms, traffic, source)
             if world > 1:
-                out["roofline"]["note"] = ("rank 0's slab; stream time per double step including waits "
+                out["roofline"]["note"] = ("rank 0's slab; stream time per launch including waits "
                                            "for halo columns, not the bare kernel")
             elif args.form == "triple":
                 out["roofline"]["note"] = ("the kernel is bound by vector-instruction issue, not by HBM: the fraction says how "

@@ -695,6 +695,10 @@ class CSlabRun:
     def double_step(self):
         self.slb.lib().slb_slabs_double_step(self.r, None, None)
 
+    def multi_step(self, S):
+        """S = 2 or 3 iterations per launch (3: ring_step_kernel); 11 halo columns per neighbour either way."""
+        self.slb.lib().slb_slabs_multi_step(self.r, S, None)
+
     def step_fused(self):
         """One iteration (one launch per range) with the ghost columns brought up to date:
         what an odd number of steps ends on."""

@@ -168,9 +168,10 @@ int slb_solver_copy_av_rows(slb_solver *s, float *rows);
 int slb_solver_halo_pack_double  (slb_solver *s, float *buf_left, float *buf_right);
 int slb_solver_halo_unpack_double(slb_solver *s, float *buf_left, float *buf_right);
 /* the same for a launch of S = 1..3 steps, between its edge ranges and
- * slb_solver_multi_step_finish(): 2S-1 main-lattice columns, then 2S half-step columns, per
- * neighbour 2*(4S-1)*(N+1) floats; the new lattices are in the spare arrays for S = 2, in
- * a/b[next] and a/b[next_hs] for odd S */
+ * slb_solver_multi_step_finish(), to the full ghost depth (what any launch that follows may
+ * read): G-1 main-lattice columns, then G half-step columns, per neighbour 2*(2G-1)*(N+1)
+ * floats; the new lattices are in the spare arrays for S = 2, in a/b[next] and a/b[next_hs]
+ * for odd S.  The edge ranges must have formed those columns: the G outermost owned ones. */
 int slb_solver_halo_pack_multi  (slb_solver *s, int S, float *buf_left, float *buf_right);
 int slb_solver_halo_unpack_multi(slb_solver *s, int S, float *buf_left, float *buf_right);
 

@@ -7,7 +7,7 @@
  *
  * Per launch of S = 2 or 3 loop iterations (slb_step_fused2, slb_step_multi) and slab:
  *
- *   side stream:  edge column ranges -> pack -> { send/recv 4S-1 columns per neighbour,
+ *   side stream:  edge column ranges -> pack -> { send/recv 11 columns per neighbour,
  *                 + totals of av() on their way down the chain } -> unpack
  *   main stream:  interior column range
  *
@@ -292,16 +292,17 @@ void slb_slabs_multi_step(slb_slabs *r, int S, float *const *rows)
 {
   slb_solver *s = r->s;
   if (S != 2 && S != 3) { fprintf(stderr, "ERROR: slb_slabs_multi_step takes 2 or 3 steps per launch\n"); exit(EXIT_FAILURE); }
-  const int Q = 2 * S, even = S == 2;
+  const int even = S == 2;
   float c[16];
   MARK(r, S == 2 ? "slb_slabs_multi_step (2)" : "slb_slabs_multi_step (3)");
   r->double_steps++;
   slb_steps_cosines(s->t, S, c);
-  /* a neighbour needs this slab's outermost 2S-1 main and 2S half-step columns: the edge ranges are
-   * the 2S outermost owned columns of the last sweep, the interior the rest */
-  const int first = s->G, last_owned = s->G + s->W - 1;
-  const int lo = r->left >= 0 ? first + Q : first;
-  const int hi = r->right >= 0 ? last_owned - Q : last_owned;
+  /* a neighbour gets this slab's outermost G-1 main and G half-step columns whatever S is (the
+   * launch that follows may be one of three steps, which reads that deep): the edge ranges are
+   * the G outermost owned columns of the last sweep, the interior the rest */
+  const int first = s->G, last_owned = s->G + s->W - 1, E = s->G;
+  const int lo = r->left >= 0 ? first + E : first;
+  const int hi = r->right >= 0 ? last_owned - E : last_owned;
   if (r->nranks == 1) {
     on_stream(r->main);
     slb_solver_multi_step_range_rows(s, S, lo, hi, c, rows);
@@ -324,10 +325,10 @@ void slb_slabs_multi_step(slb_slabs *r, int S, float *const *rows)
   if (!r->side_busy || stale) HIP_OK(hipEventRecord(r->ev_main, r->main));
   HIP_OK(hipStreamWaitEvent(r->side, r->ev_main, 0));
   on_stream(r->side);
-  if (r->left >= 0)  slb_solver_multi_step_range_rows(s, S, first, first + Q - 1, c, rows);
-  if (r->right >= 0) slb_solver_multi_step_range_rows(s, S, last_owned - (Q - 1), last_owned, c, rows);
+  if (r->left >= 0)  slb_solver_multi_step_range_rows(s, S, first, first + E - 1, c, rows);
+  if (r->right >= 0) slb_solver_multi_step_range_rows(s, S, last_owned - (E - 1), last_owned, c, rows);
   check(slb_solver_halo_pack_multi(s, S, r->left >= 0 ? r->send2[0] : NULL, r->right >= 0 ? r->send2[1] : NULL), "halo pack");
-  exchange(r, r->send2, r->recv2, 2 * (size_t)(2 * Q - 1) * (size_t)(s->N + 1));
+  exchange(r, r->send2, r->recv2, 2 * (size_t)(2 * E - 1) * (size_t)(s->N + 1));
   /* interior: reads what the last halo chain wrote, writes the output arrays' interior
    * (which that chain read) */
   if (r->side_busy) HIP_OK(hipStreamWaitEvent(r->main, r->ev_side, 0));

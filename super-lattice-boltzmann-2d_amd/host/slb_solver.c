@@ -668,28 +668,28 @@ int slb_solver_halo_unpack(slb_solver *s, int which, int side, int ncols, const 
  * (3 columns) and of the new half-step lattice (4 columns), both still in the spare arrays,
  * gathered for each neighbour in one launch.  A side's buffer (NULL = no neighbour there)
  * holds 2*3*(N+1) floats of the main lattice followed by 2*4*(N+1) of the half-step one. */
-/* The same after the edge ranges of a launch of S steps (before slb_solver_multi_step_finish): 2S-1
- * columns of the new main lattice, 2S of the new half-step lattice -- in the spare arrays for
- * even S, in a/b[next] and a/b[next_hs] for odd S.  A side's buffer holds 2*(2S-1)*(N+1) floats
- * of the main lattice followed by 2*2S*(N+1) of the half-step one. */
-static int halo_multi(slb_solver *s, int S, float *buf_left, float *buf_right, int pack)
+/* The same after the edge ranges of a launch of S steps (before slb_solver_multi_step_finish): the
+ * outermost nmain columns of the new main lattice and nhalf of the new half-step lattice -- which
+ * are in the spare arrays for even S, in a/b[next] and a/b[next_hs] for odd S.  A side's buffer
+ * holds 2*nmain*(N+1) floats of the main lattice followed by 2*nhalf*(N+1) of the half-step one. */
+static int halo_multi(slb_solver *s, int S, int nmain, int nhalf, float *buf_left, float *buf_right, int pack)
 {
-  const int nrows = s->N + 1, Q = 2 * S, even = (S % 2) == 0;
+  const int nrows = s->N + 1, even = (S % 2) == 0;
   if (!buf_left && !buf_right) return 0;          /* a slab without neighbours */
-  if (S < 1 || S > 3 || (even && !s->spare_a) || s->G < Q) return -1;
+  if (S < 1 || S > 3 || (even && !s->spare_a) || nmain < 1 || nhalf < 1 || nmain > s->G || nhalf > s->G) return -1;
   slb_halo_seg seg[4];
   int k = 0;
   for (int side = 0; side < 2; side++) {
     float *buf = side == 0 ? buf_left : buf_right;
     if (!buf) continue;
     for (int lat = 0; lat < 2; lat++) {
-      const int ncols = lat == 0 ? Q - 1 : Q;
+      const int ncols = lat == 0 ? nmain : nhalf;
       seg[k].a = lat == 0 ? (even ? s->spare_a : s->a[s->next]) : (even ? s->spare_ah : s->a[s->next_hs]);
       seg[k].b = lat == 0 ? (even ? s->spare_b : s->b[s->next]) : (even ? s->spare_bh : s->b[s->next_hs]);
       seg[k].ncols = ncols;
       if (pack) seg[k].col = side == 0 ? s->G : s->G + s->W - ncols;      /* outermost owned columns */
       else      seg[k].col = side == 0 ? s->G - ncols : s->G + s->W;      /* the ghost columns next to them */
-      seg[k].buf = buf + (lat == 0 ? 0 : 2 * (Q - 1) * nrows);
+      seg[k].buf = buf + (lat == 0 ? 0 : 2 * nmain * nrows);
       k++;
     }
   }
@@ -699,24 +699,26 @@ static int halo_multi(slb_solver *s, int S, float *buf_left, float *buf_right, i
   return rc;
 }
 
+/* full depth: G-1 main and G half-step columns, what ANY launch that follows may read */
 int slb_solver_halo_pack_multi(slb_solver *s, int S, float *buf_left, float *buf_right)
 {
-  return halo_multi(s, S, buf_left, buf_right, 1);
+  return halo_multi(s, S, s->G - 1, s->G, buf_left, buf_right, 1);
 }
 
 int slb_solver_halo_unpack_multi(slb_solver *s, int S, float *buf_left, float *buf_right)
 {
-  return halo_multi(s, S, buf_left, buf_right, 0);
+  return halo_multi(s, S, s->G - 1, s->G, buf_left, buf_right, 0);
 }
 
+/* the depth another double step reads: 3 and 4 columns */
 int slb_solver_halo_pack_double(slb_solver *s, float *buf_left, float *buf_right)
 {
-  return halo_multi(s, 2, buf_left, buf_right, 1);
+  return halo_multi(s, 2, 3, 4, buf_left, buf_right, 1);
 }
 
 int slb_solver_halo_unpack_double(slb_solver *s, float *buf_left, float *buf_right)
 {
-  return halo_multi(s, 2, buf_left, buf_right, 0);
+  return halo_multi(s, 2, 3, 4, buf_left, buf_right, 0);
 }
 
 /* this slab's share of the three av() sums over its own columns of the CURRENT main

@@ -2,7 +2,7 @@
 inherited sockets: started by tests/test_slabs_c_gpu.py, one process per rank, all on one GPU.
 
 usage: slab_c_worker.py RANK NRANKS OUTDIR PLAN N M B OMEGA FD_0 ... FD_{NRANKS-1}
-PLAN: letters d (double step), s (single step with a ghost refresh), l (last step)
+PLAN: letters t (three steps in one launch), d (double step), s (single step with a ghost refresh), l (last step)
 FD_q: this rank's socket to rank q (-1 for itself)
 """
 import ctypes as C
@@ -36,7 +36,9 @@ def main():
     assert r
     L.slb_slabs_tiptoe(r)
     for step in plan:
-        if step == "d":
+        if step == "t":
+            L.slb_slabs_multi_step(r, 3, None)
+        elif step == "d":
             L.slb_slabs_double_step(r, None, None)
         elif step == "s":
             L.slb_slabs_step(r)

@@ -25,19 +25,23 @@ BASE = ["display=4", "E_dc=1", "E_omega=0.1", "mu=5", "alpha=1", "PhiYmin=-4", "
     (4, ["omega=100", "B=0.5", "dt=0.001", "n-harmonics=16", "g-grid=4001", "t-max=0.03", "E_omega=0"]),   # no averaging at all
     (2, ["omega=100", "B=0.0019", "dt=0.001", "n-harmonics=64", "g-grid=2000001", "t-max=0.003"]),   # slabs of more than one round of workgroups: whole column strips first
 ])
-def test_program_over_ranks_writes_the_single_gpu_record(ranks, extra, tmp_path, solver_bin):
+@pytest.mark.parametrize("per_launch", ["2", "3"])
+def test_program_over_ranks_writes_the_single_gpu_record(ranks, extra, per_launch, tmp_path, solver_bin):
+    """Two iterations per launch (the double step), and three (the LDS-ring kernel: six ghost
+    columns' worth of halo, batches of the av chain of six lattices)."""
     args = BASE + extra
     one = subprocess.run([solver_bin] + args + ["o=one.txt"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert one.returncode == 0, one.stdout + one.stderr
     many = subprocess.run([solver_bin] + args + [f"ranks={ranks}", "o=slabs.txt"], cwd=tmp_path, capture_output=True,
-                          text=True, timeout=300)
+                          text=True, timeout=300, env={**os.environ, "SLB_STEPS_PER_LAUNCH": per_launch})
     assert many.returncode == 0, many.stdout + many.stderr
     a, b = (tmp_path / "one.txt").read_text().splitlines(), (tmp_path / "slabs.txt").read_text().splitlines()
     assert len(a) == 3 and a == b
 
 
+@pytest.mark.parametrize("per_launch", ["2", "3"])
 @pytest.mark.parametrize("ranks,grid", [(1, "4001"), (3, "4001"), (4, "70001")])
-def test_program_over_ranks_writes_the_single_gpu_trace(ranks, grid, tmp_path, solver_bin):
+def test_program_over_ranks_writes_the_single_gpu_trace(ranks, grid, per_launch, tmp_path, solver_bin):
     """display=77 over ranks: every record of the trace (sums over the CPU solver's flat index,
     averaging data rescaled in place at each record and handed back to the chain) and the norm
     log equal the single-GPU program's; single steps with a ghost refresh alternate with
@@ -47,7 +51,8 @@ def test_program_over_ranks_writes_the_single_gpu_trace(ranks, grid, tmp_path, s
     one = subprocess.run([solver_bin] + args + ["o=one.txt"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert one.returncode == 0, one.stdout + one.stderr
     many = subprocess.run([solver_bin] + args + [f"ranks={ranks}", "o=slabs.txt"], cwd=tmp_path, capture_output=True,
-                          text=True, timeout=300, env={**os.environ, **({"SLB_FORCE_SLABS": "1"} if ranks == 1 else {})})
+                          text=True, timeout=300, env={**os.environ, "SLB_STEPS_PER_LAUNCH": per_launch,
+                                                       **({"SLB_FORCE_SLABS": "1"} if ranks == 1 else {})})
     assert many.returncode == 0, many.stdout + many.stderr
     a, b = (tmp_path / "one.txt").read_text().splitlines(), (tmp_path / "slabs.txt").read_text().splitlines()
     assert len(a) == 22 and a == b
@@ -168,7 +173,7 @@ def test_single_rank_loop_in_c_matches_the_oracle(slb, oracle):
             oracle.lib().orc_av(C.byref(p), orc.array("a", cur), orc.array("b", cur), av_cpu, t_k)
         for k in range(11):                      # 11 double steps: more than two batches of the chain
             rows = (C.c_void_p * 2)()
-            L.slb_slabs_av_rows(r, 2, C.byref(rows))
+            L.slb_slabs_av_rows(r, 2, rows)
             tt = (C.c_float * 2)(s.t, np.float32(np.float32(s.t) + np.float32(p.dt)))
             L.slb_slabs_double_step(r, rows[0], rows[1])
             L.slb_slabs_av_submit(r, 2, tt, 0)
@@ -176,6 +181,20 @@ def test_single_rank_loop_in_c_matches_the_oracle(slb, oracle):
                 t_k = np.float32(t_k)
                 orc.step(1)
                 cpu_av()
+        for k in range(7):                       # launches of three; of the first only the last two lattices are averaged
+            rows = (C.c_void_p * 3)()
+            L.slb_slabs_av_rows(r, 3, rows)
+            t1 = np.float32(s.t)
+            t2 = np.float32(t1 + np.float32(p.dt))
+            t3 = np.float32(t2 + np.float32(p.dt))
+            L.slb_slabs_multi_step(r, 3, rows)
+            skip = 1 if k == 0 else 0
+            tt = (C.c_float * (3 - skip))(*[t1, t2, t3][skip:])
+            L.slb_slabs_av_submit(r, 3 - skip, tt, skip)
+            for i, t_k in enumerate((t1, t2, t3)):
+                orc.step(1)
+                if i >= skip:
+                    cpu_av()
         t_k = np.float32(s.t)
         L.slb_slabs_last_step(r)
         L.slb_slabs_av_submit_current(r, t_k)
@@ -199,6 +218,8 @@ def test_single_rank_loop_in_c_matches_the_oracle(slb, oracle):
 @pytest.mark.parametrize("ranks,plan", [
     (2, "dsdsddsl"),        # a double step right after a single step: the spares are re-copied while the side stream is busy
     (3, "sdsdddssdl"),
+    (2, "tttdtdstl"),       # launches of three write a/b[next]; a double step after an odd number of them re-copies the spares
+    (4, "ttsttdttl"),
 ])
 def test_c_loop_over_ranks_in_any_order_of_steps(ranks, plan, tmp_path, oracle):
     """slb_slabs_double_step() after slb_slabs_step() on several ranks (sockets, one GPU): the
@@ -228,7 +249,7 @@ def test_c_loop_over_ranks_in_any_order_of_steps(ranks, plan, tmp_path, oracle):
         si.close(), sj.close()
     outs = [p_.communicate(timeout=200)[0] for p_ in procs]
     assert all(p_.returncode == 0 for p_ in procs), "\n".join(outs)
-    steps = sum(2 if c == "d" else 1 for c in plan)
+    steps = sum({"t": 3, "d": 2}.get(c, 1) for c in plan)
     p = oracle.make_params(N=N, M=M, B=B, omega=omega)
     orc = oracle.OracleState(p)
     try:
