@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What the C slab driver and RCCL cost per double step, measured on ONE GPU: a slab of
+"""What the C slab driver and RCCL cost per launch of two and of three steps, measured on ONE GPU: a slab of
 2^20 columns (n-harmonics=128) stepped (a) as a lattice of its own by the plain engine,
 (b) by the slab loop with one rank (no neighbours), (c) as the middle slab of three with both
 neighbours' messages sent to the process itself over RCCL (edge launches, pack, grouped
@@ -41,27 +41,29 @@ def main():
             best = min(best, (time.perf_counter() - t0) / n)
         return best * 1e3
 
-    configure(W)
-    L.slb_set_stream(None)
-    sol = slb.Solver()
-    sol.tiptoe()
-    print(f"plain engine, one lattice of 2^20 columns:       {timed(sol.double_step, pairs):.4f} ms per double step", flush=True)
-    sol.close()
+    for S in (2, 3):
+        print(f"## {S} steps per launch", flush=True)
+        configure(W)
+        L.slb_set_stream(None)
+        sol = slb.Solver()
+        sol.tiptoe()
+        print(f"plain engine, one lattice of 2^20 columns:          {timed(lambda: sol.multi_step(S) if S == 3 else sol.double_step(), pairs):.4f} ms per launch", flush=True)
+        sol.close()
 
-    r = L.slb_slabs_create(0, 1, None)
-    L.slb_slabs_tiptoe(r)
-    print(f"slab loop in C, one rank:                         {timed(lambda: L.slb_slabs_double_step(r, None, None), pairs):.4f} ms", flush=True)
-    L.slb_slabs_destroy(r)
+        r = L.slb_slabs_create(0, 1, None)
+        L.slb_slabs_tiptoe(r)
+        print(f"slab loop in C, one rank:                           {timed(lambda: L.slb_slabs_multi_step(r, S, None), pairs):.4f} ms", flush=True)
+        L.slb_slabs_destroy(r)
 
-    configure(3 * W)
-    ident = C.create_string_buffer(128)
-    assert L.slb_link_unique_id(ident) == 0
-    link = L.slb_link_open_rccl(0, 1, ident.raw)
-    r = L.slb_slabs_create_loopback(1, 3, link)
-    L.slb_slabs_tiptoe(r)
-    print(f"slab loop in C, middle slab, RCCL messages to self: {timed(lambda: L.slb_slabs_double_step(r, None, None), pairs):.4f} ms", flush=True)
-    L.slb_slabs_destroy(r)
-    L.slb_link_close(link)
+        configure(3 * W)
+        ident = C.create_string_buffer(128)
+        assert L.slb_link_unique_id(ident) == 0
+        link = L.slb_link_open_rccl(0, 1, ident.raw)
+        r = L.slb_slabs_create_loopback(1, 3, link)
+        L.slb_slabs_tiptoe(r)
+        print(f"slab loop in C, middle slab, RCCL messages to self: {timed(lambda: L.slb_slabs_multi_step(r, S, None), pairs):.4f} ms", flush=True)
+        L.slb_slabs_destroy(r)
+        L.slb_link_close(link)
 
 
 if __name__ == "__main__":

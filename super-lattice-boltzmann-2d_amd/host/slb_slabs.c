@@ -285,6 +285,13 @@ void slb_slabs_tiptoe(slb_slabs *r)
   on_stream(r->main);
 }
 
+/* the launch for one column range: two steps are the double-step kernel's, three the ring kernel's */
+static void range_launch(slb_solver *s, int S, int j_first, int j_last, const float *c, float *const *rows)
+{
+  if (S == 2) slb_solver_double_step_range_rows(s, j_first, j_last, c, rows ? rows[0] : NULL, rows ? rows[1] : NULL);
+  else        slb_solver_multi_step_range_rows(s, S, j_first, j_last, c, rows);
+}
+
 /* S = 2 or 3 loop iterations in one launch per column range.  rows (NULL or S pointers): [3][pitch]
  * device buffers that receive the rows av() reads of the main lattice after each of the S
  * iterations, at this slab's columns. */
@@ -305,10 +312,10 @@ void slb_slabs_multi_step(slb_slabs *r, int S, float *const *rows)
   const int hi = r->right >= 0 ? last_owned - E : last_owned;
   if (r->nranks == 1) {
     on_stream(r->main);
-    slb_solver_multi_step_range_rows(s, S, lo, hi, c, rows);
+    range_launch(s, S, lo, hi, c, rows);
     HIP_OK(hipEventRecord(r->ev_main, r->main));
     exchange(r, NULL, NULL, 0);                       /* the clock of the av schedule ticks all the same */
-    slb_solver_multi_step_finish(s, S);
+    if (S == 2) slb_solver_double_step_finish(s); else slb_solver_multi_step_finish(s, S);
     return;
   }
   on_stream(r->main);
@@ -325,22 +332,22 @@ void slb_slabs_multi_step(slb_slabs *r, int S, float *const *rows)
   if (!r->side_busy || stale) HIP_OK(hipEventRecord(r->ev_main, r->main));
   HIP_OK(hipStreamWaitEvent(r->side, r->ev_main, 0));
   on_stream(r->side);
-  if (r->left >= 0)  slb_solver_multi_step_range_rows(s, S, first, first + E - 1, c, rows);
-  if (r->right >= 0) slb_solver_multi_step_range_rows(s, S, last_owned - (E - 1), last_owned, c, rows);
+  if (r->left >= 0)  range_launch(s, S, first, first + E - 1, c, rows);
+  if (r->right >= 0) range_launch(s, S, last_owned - (E - 1), last_owned, c, rows);
   check(slb_solver_halo_pack_multi(s, S, r->left >= 0 ? r->send2[0] : NULL, r->right >= 0 ? r->send2[1] : NULL), "halo pack");
   exchange(r, r->send2, r->recv2, 2 * (size_t)(2 * E - 1) * (size_t)(s->N + 1));
   /* interior: reads what the last halo chain wrote, writes the output arrays' interior
    * (which that chain read) */
   if (r->side_busy) HIP_OK(hipStreamWaitEvent(r->main, r->ev_side, 0));
   on_stream(r->main);
-  slb_solver_multi_step_range_rows(s, S, lo, hi, c, rows);
+  range_launch(s, S, lo, hi, c, rows);
   HIP_OK(hipEventRecord(r->ev_main, r->main));
   on_stream(r->side);
   check(slb_solver_halo_unpack_multi(s, S, r->left >= 0 ? r->recv2[0] : NULL, r->right >= 0 ? r->recv2[1] : NULL), "halo unpack");
   HIP_OK(hipEventRecord(r->ev_side, r->side));
   r->side_busy = 1;
   on_stream(r->main);
-  slb_solver_multi_step_finish(s, S);                 /* the output arrays become the current lattices */
+  if (S == 2) slb_solver_double_step_finish(s); else slb_solver_multi_step_finish(s, S);                 /* the output arrays become the current lattices */
 }
 
 /* Two loop iterations.  rows_first / rows_second (both or neither): [3][pitch] device
