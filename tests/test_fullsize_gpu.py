@@ -175,6 +175,101 @@ def test_full_shape_double_step_windows_bit_exact(slb, oracle, N, M, with_rows):
         sol.close()
 
 
+def _check_multi_step_on_window(sol, slb, oracle, p, c0, c1, S, rows=None):
+    """S iterations per launch held to the oracle directly: columns [c0, c1] of all nine arrays
+    before the launch, the launch on the GPU, then its 2S sweeps replayed on the window with the
+    oracle.  The lattice a sweep writes starts from the buffer the reference's ping-pong would
+    have put it in (a/b[next], a/b[next_hs], a/b[current], a/b[current_hs], a/b[next], ...), so
+    every cell no sweep writes is what the reference finds there."""
+    s = sol.s
+    M, ncols, Q = p.M, c1 - c0 + 1, 2 * S
+    before = [sol.window(k, c0, ncols) for k in ALL]
+    cur, nxt, chs, nhs = s.current, s.next, s.current_hs, s.next_hs
+    t_before = s.t
+    cos = slb.steps_cosines(s.t, S)
+    if rows is None:
+        sol.multi_step(S)
+    else:
+        sol.multi_step_rows(S, [r.data_ptr() for r in rows])
+    a0 = before[0]
+    A = lambda i: before[1 + i]
+    B = lambda i: before[5 + i]
+    rng = _stage_ranges(c0, c1, M, Q)
+    outs, where = [], []
+    for q in range(Q):
+        into_next = (q // 2) % 2 == 0
+        idx = (nxt if into_next else cur) if q % 2 == 0 else (nhs if into_next else chs)
+        oa, ob = A(idx).copy(), B(idx).copy()
+        ca, cb = (A(cur), B(cur)) if q == 0 else ((A(chs), B(chs)) if q == 1 else outs[q - 2])
+        sa, sb = (A(chs), B(chs)) if q == 0 else outs[q - 1]
+        oracle.sweep(p, ncols, c0, rng[q][0] - c0, rng[q][1] - c0, a0, ca, cb, sa, sb, oa, ob, cos[2 * q], cos[2 * q + 1])
+        outs.append((oa, ob))
+        where.append(idx)
+    assert (s.current, s.current_hs) == (where[Q - 2], where[Q - 1])
+    assert s.t != t_before
+    for q in (Q - 2, Q - 1):
+        lo, hi = rng[q]
+        for base, exp, name in ((1, outs[q][0], "a"), (5, outs[q][1], "b")):
+            got = sol.window(base + where[q], lo, hi - lo + 1)
+            assert np.array_equal(got.view(np.uint32), exp[:, lo - c0:hi - c0 + 1].view(np.uint32)), (name, q, lo, hi)
+    if rows is not None:
+        import torch
+        torch.cuda.synchronize()
+        for i in range(S):                        # the three rows av() reads of the lattice after iteration i
+            lo, hi = rng[2 * i]
+            hi = min(hi, M)                       # av() sums columns 1..M
+            ea, eb = outs[2 * i]
+            got = rows[i][:, lo:hi + 1].cpu().numpy()
+            exp = np.stack([ea[0, lo - c0:hi - c0 + 1], ea[1, lo - c0:hi - c0 + 1], eb[1, lo - c0:hi - c0 + 1]])
+            assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), ("rows", i, lo, hi)
+
+
+@pytest.mark.parametrize("with_rows", [False, True])
+@pytest.mark.parametrize("N,M", [
+    (128, 1 << 20),          # config 3: 2.1 rounds of workgroups of the ring kernel
+    (512, 1 << 20),          # config 5
+    (128, 1 << 23),          # config 4 on a single GPU
+    (128, 800003),
+    (64, 1 << 19),           # the narrowest lattice the program runs in threes
+    (33, 600011),            # odd row count, ragged right edge
+])
+def test_full_shape_triple_step_windows_bit_exact(slb, oracle, N, M, with_rows):
+    """The default of the program and of the benchmark on wide lattices -- three iterations per
+    launch, ring_step_kernel: stage outputs in an LDS ring, branch-free steady passes with the
+    next pass's rows requested ahead, edge strip groups first in short chunks, whole strips next,
+    the rest in chunks -- against the oracle's six sweeps, no other HIP kernel in between
+    (reference: src/boltzmann_c_solver.c:164-194, 355-411).  Windows: both ends of the lattice
+    (the edge groups), the centre, the seam between the first edge group and the whole strips,
+    and the columns where a round of 512 workgroups of 960 columns ends."""
+    import torch
+    p = oracle.make_params(N=N, M=M, B=4000.0 / M, omega=100.0)
+    slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    sol = slb.Solver()
+    try:
+        assert sol.steps_per_launch() == 3
+        sol.tiptoe()
+        sol.step()
+        rows = None
+        if with_rows:
+            rows = [torch.zeros((3, sol.s.pitch), dtype=torch.float32, device="cuda") for _ in range(3)]
+        windows = [(0, 600), (M - 500, M + 2), (M // 2 - 300, M // 2 + 300), (960 - 300, 960 + 300)]
+        seam = 512 * 960
+        for k in range(1, 18):
+            if 960 + k * seam + 400 < M:
+                windows.append((960 + k * seam - 400, 960 + k * seam + 400))
+        windows = windows[:7]
+        for c0, c1 in windows:
+            _check_multi_step_on_window(sol, slb, oracle, p, c0, c1, 3, rows)
+        _check_multi_step_on_window(sol, slb, oracle, p, 0, 600, 2)       # a double step in between: the spares follow
+        _check_multi_step_on_window(sol, slb, oracle, p, M - 500, M + 2, 3, rows)
+        row0 = sol.rows(1 + sol.s.current, 0, 1)[0]
+        norm = 2 * np.pi * np.sqrt(p.alpha) * np.sum(row0[1:M + 1].astype(np.float64) * p.dPhi)
+        assert abs(norm - 1) < 2e-4
+    finally:
+        sol.close()
+
+
 def _rows_to_compare(N, M):
     """All rows of a lattice that fits comfortably, otherwise the rows around every place a
     workgroup's chunk of rows may begin or end, the first and last rows, and every 16th."""
