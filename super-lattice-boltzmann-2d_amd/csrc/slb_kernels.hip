@@ -1661,14 +1661,15 @@ pipe_step_kernel(const PipeArgs<S> p)
 // end of a strip, single-column stores at a ragged right edge), so every wait in it had to be a
 // wait for ALL outstanding accesses -- the previous pass's stores included -- and loads issued a
 // pass ahead could not stay in flight.  Here a wave first asks whether any of its lanes ever
-// needs those cases (only the waves at the two ends of the lattice do); if none does, the passes in
-// which every stage is active, stores, and is past rows 0 and 1 run a body without a single
-// branch: the five input rows of pass r+1 are requested at the top of pass r (the row loop is
+// needs those cases (only the waves at the two ends of the lattice do); if none does, every pass up to
+// the one that meets row N runs a body whose only branches are on the row number (rows 0 and 1) and
+// hold no loads: the five input rows of pass r+1 are requested at the top of pass r (the row loop is
 // unrolled by two, so the two register sets just alternate and the ring slots have fixed
 // addresses), stores of halo lanes are dropped by the buffer bounds check (their offset lies
 // beyond the row's end) instead of by a branch, and the only wait for memory is the one that lets
-// the four stores of the pass before stay outstanding.  The first and last passes of a strip, and
-// all passes of the edge waves, run the general body (the RING body of pipe_step_kernel).
+// the four stores of the pass before stay outstanding.  The last passes of a strip (row N is fetched,
+// stages run out of rows) and all passes of the edge waves run the general body (the RING body of
+// pipe_step_kernel).
 // Same stages, same hand-offs, same point update: same bits.
 //
 // ROWS: as in the double step, rows 0 and 1 of a and row 1 of b of every new main lattice
@@ -1766,8 +1767,9 @@ ring_step_kernel(const RingArgs<S> ra)
     const slb_f4 x = __builtin_bit_cast(slb_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, off_ld, 0, 0));
     v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
   };
-  auto bstore4 = [&](float *base, size_t row, const float (&v)[V]) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(base + row), 0, row_bytes, kRsrcFlags);
+  auto bstore4 = [&](float *base, size_t row, const float (&v)[V], bool live) {
+    // (a row that is not to be stored gets a descriptor of length zero: every lane's store is dropped)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(base + row), 0, live ? row_bytes : 0, kRsrcFlags);
     const slb_f4 x = {v[0], v[1], v[2], v[3]};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(slb_u4, x), rs, off_st, 0, 2);    // 2: non-temporal
   };
@@ -1837,7 +1839,7 @@ ring_step_kernel(const RingArgs<S> ra)
         if (q == 0) { widen(cur.upA, ea); widen(cur.upB, eb); diffs(hA[1], la); diffs(hB[1], lb); }
         else        { widen(nA[q >= 1 ? q - 1 : 0], ea); widen(nB[q >= 1 ? q - 1 : 0], eb);
                       diffs(oldA[q >= 1 ? q - 1 : 0], la); diffs(oldB[q >= 1 ? q - 1 : 0], lb); }
-        if (!ST && n < 2) {                        // the same for the whole wave; rows 0 and 1 only
+        if (n < 2) {                               // the same for the whole wave; rows 0 and 1 only (and rows < 0 of a strip's first passes)
           asm volatile("" ::);
 #pragma unroll
           for (int k = 0; k < V; k++) { lb[k] = 0.0f; la[k] = n == 0 ? 0.0f : 2.0f * la[k]; }
@@ -1864,14 +1866,15 @@ ring_step_kernel(const RingArgs<S> ra)
                                   slb_f2{la[k], la[k + 1]}, slb_f2{lb[k], lb[k + 1]}, qa, qb);
           nA[q][k] = qa.x; nA[q][k + 1] = qa.y; nB[q][k] = qb.x; nB[q][k + 1] = qb.y;
         }
-        const size_t row = (size_t)n * P;
+        const size_t row = (size_t)(n > 0 ? n : 0) * P;
         if constexpr (ST) {
           // (one stage at a time: left to itself the scheduler interleaves the stages of the branch-free
           // body for parallelism it has no registers for)
           __builtin_amdgcn_sched_barrier(0);
           if (q >= Q - 2 && X != 2) {
-            bstore4(q == Q - 2 ? p.a_o : p.a_ho, row, nA[q]);
-            bstore4(q == Q - 2 ? p.b_o : p.b_ho, row, nB[q]);
+            const bool mine = n >= n0 && n < n1;       // (a strip's first passes form rows before its own, or before row 0)
+            bstore4(q == Q - 2 ? p.a_o : p.a_ho, row, nA[q], mine);
+            bstore4(q == Q - 2 ? p.b_o : p.b_ho, row, nB[q], mine && n > 0);
           }
           if (q < Q - 1) { ring_put(par, q, 0, nA[q]); ring_put(par, q, 1, nB[q]); }
         } else {
@@ -1891,19 +1894,6 @@ ring_step_kernel(const RingArgs<S> ra)
               }
             }
           }
-          if constexpr (ROWS) {
-            // a main lattice's rows 0 and 1 come from the chunk that starts at row 0
-            if ((q & 1) == 0 && n <= 1 && n0 == 0 && interior) {
-              float *rows = ra.rows[q >> 1];
-#pragma unroll
-              for (int k = 0; k < V; k++) {
-                if ((q == Q - 2 ? (wr >> k) & 1u : (ok >> (q * V + k)) & 1u)) {
-                  rows[row + j + k] = nA[q][k];
-                  if (n == 1) rows[2 * P + j + k] = nB[q][k];
-                }
-              }
-            }
-          }
           if (q < Q - 1) {
             if (need & (1u << q)) {
               float xa[V], xb[V];
@@ -1913,6 +1903,22 @@ ring_step_kernel(const RingArgs<S> ra)
                 if (!(ok & (1u << (q * V + k)))) { nA[q][k] = xa[k]; nB[q][k] = xb[k]; }
             }
             ring_put(par, q, 0, nA[q]); ring_put(par, q, 1, nB[q]);
+          }
+        }
+        if constexpr (ROWS) {
+          // a main lattice's rows 0 and 1 come from the chunk that starts at row 0 (a branch the whole wave
+          // takes or not, in the first passes of a strip only)
+          if ((q & 1) == 0 && n >= 0 && n <= 1 && n0 == 0) {
+            if (interior) {
+              float *rows = ra.rows[q >> 1];
+#pragma unroll
+              for (int k = 0; k < V; k++) {
+                if ((q == Q - 2 ? (wr >> k) & 1u : (ok >> (q * V + k)) & 1u)) {
+                  rows[row + j + k] = nA[q][k];
+                  if (n == 1) rows[2 * P + j + k] = nB[q][k];
+                }
+              }
+            }
           }
         }
       } else if (q < Q - 1 && n == p.N) {
@@ -1944,10 +1950,14 @@ ring_step_kernel(const RingArgs<S> ra)
   // and the two last stages store all four of its columns or none
   const bool lane_plain = need == 0 && (wr == 0xffu || wr == 0u);
   const bool wave_plain = __builtin_amdgcn_ballot_w64(lane_plain) == ~0ull;
-  // passes r in [s0, s1): every stage active at a row >= 2, both last stages inside the chunk, and
-  // row r+1 still a row the sweeps read (so that the request a pass ahead stays inside the arrays)
-  int s0 = n0 + Q - 1 > Q + 1 ? n0 + Q - 1 : Q + 1;
-  s0 += s0 & 1;                                                 // a pair of passes starts at an even row
+  // passes r in [s0, s1): from the strip's first pass (a pair of passes starts at an even row) to the last
+  // one in which row r+1 is still a row the sweeps read (so that the request a pass ahead stays inside the
+  // arrays).  In a strip's first passes the later stages run on rows before the strip's own, or before row 0
+  // (their row index clamped for addressing): what they form is stored nowhere (a descriptor of length
+  // zero) and read by no stage at a row that counts -- stage q+1 reads stage q's row n-1 only at its own
+  // rows n >= 2 and stage q+2 reads row n as its centre, both of which stage q formed when it was already
+  // at rows of its own.
+  int s0 = a_lo + (a_lo & 1);
   const int s1 = n1 + Q - 2 < p.N - 1 ? n1 + Q - 2 : p.N - 1;
 
   RowIn x = {}, y = {};
