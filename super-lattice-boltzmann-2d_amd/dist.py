@@ -6,7 +6,9 @@ The reference is single-GPU; this driver is additive.  Coupling along phi_y is
 +-1 column on the lattice a sweep reads as stencil (reference:
 src/boltzmann_c_solver.c:370-372), and that lattice is the one the PREVIOUS
 sweep wrote.  Ranks form a non-periodic chain: rank r talks to r-1 and r+1.
-A slab keeps G = 4 ghost columns per side; owned columns are G .. G+W-1.
+A slab keeps G ghost columns per side (the engine's choice: 6 in host/slb_solver.c, so that the C slab
+loop can take three steps per launch; the forms of this driver read at most 4 deep); owned columns are
+G .. G+W-1.
 
 Three step forms, bit-identical to each other and to a single-domain run:
 
