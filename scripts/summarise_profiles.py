@@ -30,7 +30,7 @@ def main():
     os.makedirs(dst, exist_ok=True)
     traffic = {"_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; "
                         "FETCH_SIZE doubled per the gfx950 note; KiB units) of `python3 bench.py --no-cpu "
-                        "--no-two-sweep --repeats 1 ...`; scripts/profile_r03.sh (profile_r02.sh in round 2), scripts/summarise_profiles.py"}
+                        "--no-two-sweep --repeats 1 ...`; scripts/profile_r03.sh (or the earlier profile_r02.sh), scripts/summarise_profiles.py"}
     summary = {}
     for log in sorted(glob.glob(os.path.join(src, "trace_*.log"))):
         tag = os.path.basename(log)[len("trace_"):-len(".log")]

@@ -2,7 +2,7 @@
 in the reference's shape -- it defines host_E_dc ... PADDED_MSIZE itself (reference:
 src/boltzmann_cli.c:20-45, src/boltzmann_solver.c:47-65), owns all device memory and calls
 load_data / step_on_grid / step_on_half_grid / av / HandleError -- linked against libslb2d.so
-with the line INTEGRATION.md gives, with and without -rdynamic.  libslb2d.so carries
+with the documented link line (-lslb2d), with and without -rdynamic.  libslb2d.so carries
 definitions of the same globals (for foreign-function callers); the test shows that
 load_data() inside the library reads the EXECUTABLE's copies: the executable never touches the
 library's, which stay zero, and a library that read its own would refuse to launch.  A second
