@@ -59,6 +59,18 @@ def _run_both(solver_bin, oracle, tmp_path, args, extra_files=(), stdin_text=Non
 COMMON = ["E_dc=1", "E_omega=0.1", "mu=5", "alpha=1", "PhiYmin=-4", "PhiYmax=4", "dt=0.001"]
 
 
+PER_LAUNCH = pytest.mark.parametrize("per_launch", [None, "3"], ids=["default", "three-per-launch"])
+
+
+def _per_launch_env(per_launch, env=None):
+    """The environment that forces that many time steps into each launch wherever the program's
+    schedule allows it (three is otherwise chosen only on wide lattices)."""
+    env = dict(env or {})
+    if per_launch is not None:
+        env["SLB_STEPS_PER_LAUNCH"] = per_launch
+    return env or None
+
+
 def test_program_display4_identical(solver_bin, oracle, tmp_path):
     args = ["display=4", "omega=100", "B=1", "n-harmonics=32", "g-grid=4096", "t-max=0.05"] + COMMON
     gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
@@ -120,11 +132,12 @@ def test_program_display4_tree_sums_within_rounding_noise(solver_bin, oracle, tm
         assert abs(float(ca[i]) - float(cb[i])) <= 1e-4 * scale + 1e-9, (i, ca[i], cb[i])   # the float sum is that noisy
 
 
-def test_program_display77_identical(solver_bin, oracle, tmp_path):
+@PER_LAUNCH
+def test_program_display77_identical(solver_bin, oracle, tmp_path, per_launch):
     """display=77 trace on a shrunken config-2 shape: every record identical,
     including the flat-index sums and the in-place rescaling of the averages."""
     args = ["display=77", "omega=100", "B=0.12", "n-harmonics=64", "g-grid=32768", "t-max=0.05"] + COMMON
-    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args, env=_per_launch_env(per_launch))
     got, exp = (gdir / "out.txt").read_text(), (odir / "out.txt").read_text()
     assert len(exp.splitlines()) == 22          # 11 records of header + data
     assert got == exp
@@ -179,15 +192,16 @@ def test_program_display4_config3_shape_averaged_throughout(solver_bin, oracle, 
         assert (gdir / "out.txt").read_text() == exp, form
 
 
-def test_program_display8_identical(solver_bin, oracle, tmp_path):
+@PER_LAUNCH
+def test_program_display8_identical(solver_bin, oracle, tmp_path, per_launch):
     args = ["display=8", "omega=100", "B=0.5", "n-harmonics=8", "g-grid=61", "t-max=0.01"] + COMMON
-    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args, env=_per_launch_env(per_launch))
     got, exp = (gdir / "frame.data").read_text(), (odir / "frame.data").read_text()
     assert len(exp.splitlines()) == 629 * 62 + 2
     assert got == exp
 
 
-@pytest.mark.parametrize("form,mode", [("double", None), ("fused", None), ("sweeps", None),
+@pytest.mark.parametrize("form,mode", [("double", None), ("fused", None), ("sweeps", None), ("triple", None), ("triple", "fixed"),
                                        ("double", "fixed"), ("double", "cpu"), ("sweeps", "cuda")])
 def test_program_read_from_stdin_goes_on_with_new_parameters(solver_bin, oracle, tmp_path, form, mode):
     """read-from=stdin: after each display=4 record one parameter is replaced and the run
@@ -200,7 +214,9 @@ def test_program_read_from_stdin_goes_on_with_new_parameters(solver_bin, oracle,
             "read-from=stdin"] + COMMON
     records = "E_dc 1.5 0.02\nB 0.4 0.013\nomega 50 0.01\nbogus 1 0.005\nexit\n"
     env = {}
-    if form != "double":
+    if form == "triple":
+        env["SLB_STEPS_PER_LAUNCH"] = "3"
+    elif form != "double":
         env["SLB_FORM"] = form
     if mode is not None:
         env["SLB_REPARAM"] = mode
@@ -217,10 +233,11 @@ def test_program_read_from_stdin_goes_on_with_new_parameters(solver_bin, oracle,
         assert float(rec[1][0]) == 1.5 and float(rec[3][2]) == 50.0
 
 
-def test_program_display7_movie_frames_identical(solver_bin, oracle, tmp_path):
+@PER_LAUNCH
+def test_program_display7_movie_frames_identical(solver_bin, oracle, tmp_path, per_launch):
     """display=7: a frame file every 0.01 of time once t > frame-start, same names and text."""
     args = ["display=7", "omega=100", "B=0.5", "n-harmonics=6", "g-grid=37", "t-max=0.02", "frame-start=0.03"] + COMMON
-    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args, env=_per_launch_env(per_launch))
     names = sorted(f.name for f in odir.glob("frame*.data"))
     assert names == sorted(f.name for f in gdir.glob("frame*.data")) and len(names) >= 4
     for n in names:
@@ -229,11 +246,12 @@ def test_program_display7_movie_frames_identical(solver_bin, oracle, tmp_path):
            [l for l in o.stdout.splitlines() if l.startswith("Writing")]
 
 
-def test_program_display9_strobe_identical(solver_bin, oracle, tmp_path):
+@PER_LAUNCH
+def test_program_display9_strobe_identical(solver_bin, oracle, tmp_path, per_launch):
     """display=9: 101 periods, one accumulated strobe image per period; the last file
     carries the sum of all of them."""
     args = ["display=9", "omega=100", "B=0.5", "n-harmonics=4", "g-grid=13", "t-max=0.02"] + COMMON
-    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args, env=_per_launch_env(per_launch))
     names = sorted(f.name for f in odir.glob("strobe*.data"))
     assert names == sorted(f.name for f in gdir.glob("strobe*.data")) and len(names) == 101
     for n in (names[0], names[1], names[50], names[-1]):
@@ -242,10 +260,11 @@ def test_program_display9_strobe_identical(solver_bin, oracle, tmp_path):
     assert (gdir / "out.txt").read_text() == (odir / "out.txt").read_text() == ""
 
 
-def test_program_display3_dump_identical(solver_bin, oracle, tmp_path):
+@PER_LAUNCH
+def test_program_display3_dump_identical(solver_bin, oracle, tmp_path, per_launch):
     """display=3: the final distribution and the equilibrium one, columns 1..M-1."""
     args = ["display=3", "omega=100", "B=0.5", "n-harmonics=8", "g-grid=61", "t-max=0.01"] + COMMON
-    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args)
+    gdir, odir, g, o = _run_both(solver_bin, oracle, tmp_path, args, env=_per_launch_env(per_launch))
     got, exp = (gdir / "out.txt").read_text(), (odir / "out.txt").read_text()
     assert len(exp.splitlines()) == 629 * 60 + 1
     assert got == exp
