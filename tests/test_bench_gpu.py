@@ -126,3 +126,5 @@ def test_bench_takes_odd_step_counts(gpus, steps, warmup):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == gpus and d["steps"] == steps and d["warmup"] == warmup and d["value"] > 0
+    # the launch time of the dominant kernel comes from blocks of whole launches whatever --steps is
+    assert d["roofline"]["kernel"] == "ring_step_kernel" and d["roofline"]["avg_launch_ms"] > 0
