@@ -524,6 +524,74 @@ def test_multi_step_hands_out_the_rows_av_reads(slb, oracle, S, N, M, B, omega, 
         orc.close()
 
 
+def _hip_runtime():
+    import ctypes
+    with open("/proc/self/maps") as f:
+        paths = sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    hip = ctypes.CDLL(paths[0])
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    return hip
+
+
+def _hostile_field(rng, rows, cols):
+    """Values no smooth run holds side by side: magnitudes from the smallest denormal to 1e30 next to
+    each other, both zeros, isolated denormals.  (No infinities or NaN: which NaN an invalid operation
+    makes is the processor's choice, not the algorithm's.)"""
+    x = rng.standard_normal((rows, cols)) * 10.0 ** rng.uniform(-46, 30, (rows, cols))
+    x = x.astype(np.float32)
+    r = rng.random((rows, cols))
+    x[r < 0.02] = 0.0
+    x[(r >= 0.02) & (r < 0.04)] = -0.0
+    x[(r >= 0.04) & (r < 0.05)] = np.float32(1e-41)
+    x[(r >= 0.05) & (r < 0.06)] = np.float32(-1.4e-45)
+    return x
+
+
+@pytest.mark.parametrize("S", [1, 2, 3])
+@pytest.mark.parametrize("N,M,B,omega,n_chunk", [(5, 61, 0.05, 100.0, 0), (16, 1000, 0.3, 10.0, 0), (33, 9001, 0.5, 30.0, 5),
+                                                 (24, 130001, 0.02, 30.0, 0)])
+def test_multi_step_bit_exact_on_hostile_fields(slb, oracle, S, N, M, B, omega, n_chunk):
+    """The same lattices of wild values (denormals beside 1e30, both zeros) in the engine and in the
+    oracle, a0 included, then launches of S iterations against single oracle steps: the point update's
+    divisions meet numerators of every size, the halo lanes and the row patches meet data that is not
+    smooth.  The last shape is wide enough for the whole-strips-first launch schedule."""
+    p = oracle.make_params(N=N, M=M, B=B, omega=omega)
+    slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
+                  B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
+    orc = oracle.OracleState(p)
+    sol = slb.Solver()
+    L = slb.lib()
+    hip = _hip_runtime()
+    rng = np.random.default_rng(1000 * S + N)
+    try:
+        sol.tiptoe()
+        s = sol.s
+        pitch = s.pitch
+        for which, i, ptr in [("a0", 0, s.a0)] + [("a", i, s.a[i]) for i in range(4)] + [("b", i, s.b[i]) for i in range(4)]:
+            x = _hostile_field(rng, N + 1, M + 3)
+            orc.array(which, i)[:] = x
+            padded = np.zeros((N + 1, pitch), np.float32)
+            padded[:, :M + 3] = x
+            assert hip.hipMemcpy(ptr, padded.ctypes.data, padded.nbytes, 1) == 0          # host to device
+        L.slb_set_tuning(0, n_chunk, 0)
+        for _ in range(2):
+            sol.multi_step(S)
+        orc.step(2 * S)
+        _compare_live_state(sol, orc, M)
+        sol.step(); sol.multi_step(S)
+        orc.step(1 + S)
+        _compare_live_state(sol, orc, M)
+        sol.double_step(); sol.step_fused()          # the hand-written two-step kernel and the one-step launch
+        orc.step(3)
+        _compare_live_state(sol, orc, M)
+        for which, i, arr in (("a", s.current, 1 + s.current), ("b", s.current_hs, 5 + s.current_hs)):
+            assert np.isfinite(sol.rows(arr)[:, :M + 3]).all(), "the comparison is meant to be between finite values"
+    finally:
+        L.slb_set_tuning(0, 0, 0)
+        sol.close()
+        orc.close()
+
+
 @pytest.mark.parametrize("seed", [1, 20251111])
 def test_shared_reciprocal_division_is_the_ieee_division(slb, seed):
     """div2_shared (one refined reciprocal for the two quotients of a point, hardware scaling of
