@@ -549,12 +549,13 @@ def _hostile_field(rng, rows, cols):
 
 @pytest.mark.parametrize("S", [1, 2, 3])
 @pytest.mark.parametrize("N,M,B,omega,n_chunk", [(5, 61, 0.05, 100.0, 0), (16, 1000, 0.3, 10.0, 0), (33, 9001, 0.5, 30.0, 5),
-                                                 (24, 130001, 0.02, 30.0, 0)])
+                                                 (24, 130001, 0.02, 30.0, 0), (8, 520001, 0.005, 30.0, 0)])
 def test_multi_step_bit_exact_on_hostile_fields(slb, oracle, S, N, M, B, omega, n_chunk):
     """The same lattices of wild values (denormals beside 1e30, both zeros) in the engine and in the
     oracle, a0 included, then launches of S iterations against single oracle steps: the point update's
     divisions meet numerators of every size, the halo lanes and the row patches meet data that is not
-    smooth.  The last shape is wide enough for the whole-strips-first launch schedule."""
+    smooth.  The last shape is wide enough for the launch schedule of the full-size lattices (the two
+    edge strip groups first, then one round of whole column strips, the rest in row chunks)."""
     p = oracle.make_params(N=N, M=M, B=B, omega=omega)
     slb.configure(N=N, M=M, E_dc=p.E_dc, E_omega=p.E_omega, omega=p.omega, mu=p.mu, alpha=p.alpha,
                   B=p.B, PhiYmin=p.PhiYmin, PhiYmax=p.PhiYmax, dt=p.dt)
