@@ -25,7 +25,7 @@ all: lib bin/boltzmann_solver bin/dropin_host bin/dropin_host_rdynamic oracle
 
 lib: $(LIB)
 
-$(PKG)/csrc/slb_kernels.o: $(PKG)/csrc/slb_kernels.hip $(HDRS)
+$(PKG)/csrc/slb_kernels.o: $(PKG)/csrc/slb_kernels.hip $(wildcard $(PKG)/csrc/*.inc) $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(PKG)/host/%.o: $(PKG)/host/%.c $(HDRS)
