@@ -206,6 +206,18 @@ int slb_step_fused2_factored(const slb_step2_geom *geom, const float *a0, const 
  * 4 floats) the first such numerator, denominator and the two results. */
 int slb_selftest_division(unsigned long long count, unsigned seed, unsigned long long *differ, float *first_bad);
 
+/* Test hook, host arithmetic only (no GPU call; no counterpart in the reference): the launch
+ * schedule a multi-step kernel would get for rows 0..N-1 and columns col_first..col_last on a
+ * device that holds `slots` of its workgroups at once (0: unknown), and who forms what under it.
+ * kind 2: the double step's schedule; 3: the S-step kernels' (steps = 2 or 3) with the two edge
+ * strip groups first; 4: the same without.  block: threads per workgroup; n_chunk > 0: every
+ * strip group cut into chunks of that many rows.  Returns the number of workgroups (< 0: bad
+ * arguments, a strip group out of range, cover too short); info[0..3] = strip groups, phases,
+ * columns per strip group, first column of strip group 0; cover[g * N + n] = how many workgroups
+ * form row n of strip group g -- a correct schedule leaves 1 everywhere. */
+int slb_debug_schedule(int kind, int steps, int N, int col_first, int col_last, int block, int n_chunk,
+                       int slots, int *info, int *cover, int cover_len);
+
 /* Geometry of S = `steps` loop iterations in one launch (1 <= S <= 4): the
  * columns each of the 2S sweeps produces, in execution order (main sweep at t,
  * half-step sweep at t, main sweep at t+dt, ...). */

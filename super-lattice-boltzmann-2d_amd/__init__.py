@@ -29,7 +29,7 @@ ABI_FUNCTIONS = ("load_data", "step_on_grid", "step_on_half_grid", "av", "Handle
                  "slb_frame_values", "slb_seq_sum", "slb_seq_sum_stats",
                  "slb_av_update", "slb_set_av_mode", "slb_set_stream", "slb_get_stream", "slb_push_stream", "slb_pop_stream",
                  "slb_set_tuning", "slb_version", "slb_static_init", "slb_av_static",
-                 "slb_a0_factors_check", "slb_step_fused2_factored", "slb_selftest_division")
+                 "slb_a0_factors_check", "slb_step_fused2_factored", "slb_selftest_division", "slb_debug_schedule")
 ABI_GLOBALS = ("host_E_dc", "host_E_omega", "host_omega", "host_mu", "host_alpha",
                "PhiYmin", "PhiYmax", "host_B", "t_start", "host_dPhi", "host_dt",
                "host_bdt", "host_nu_tilde", "host_nu2", "host_nu",
@@ -110,6 +110,8 @@ def lib():
         L.slb_a0_factors_check.argtypes, L.slb_a0_factors_check.restype = [fp, i, i, i, i, fp, fp, fp], i
         L.slb_selftest_division.argtypes = [C.c_ulonglong, C.c_uint, fp, fp]
         L.slb_selftest_division.restype = i
+        L.slb_debug_schedule.argtypes = [i] * 8 + [C.POINTER(C.c_int)] * 2 + [i]
+        L.slb_debug_schedule.restype = i
         L.slb_step_multi.argtypes = [C.POINTER(MultiGeom), fp, C.POINTER(C.c_void_p * 4), C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p * 4), C.POINTER(C.c_float)]
         L.slb_step_multi.restype = i

@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #include "../../include/slb_abi.h"
@@ -203,8 +204,8 @@ int resident_workgroups(K kernel, int block)
 // and only the groups left over are cut into chunks (`tail_chunk` rows, or shorter ones when
 // the lattice has few rounds); narrower lattices are cut into chunks of `tail_chunk` rows
 // throughout.
-template <int MINW, bool DIAG = false, bool ROWS = false, int H = 2, bool NTS = true, bool NTL = false, int A0F = 0, int OPT = 0>
-int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
+// `slots`: workgroups of the kernel the device holds at once (0: unknown).  H: halo lanes per side.
+void schedule_fused2(Fused2Args &args, int H, int block, int n_chunk, int tail_chunk, int slots)
 {
   int lo = args.jf[0], hi = args.jl[0];
   for (int q = 1; q < 4; q++) { lo = args.jf[q] < lo ? args.jf[q] : lo; hi = args.jl[q] > hi ? args.jl[q] : hi; }
@@ -214,8 +215,7 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
   const int wpb = block / 64;
   const int groups = (waves + wpb - 1) / wpb;
   auto chunks_of = [&](int len) { return (args.N + len - 1) / len; };
-  // (tuning variant 39: as if the occupancy query had failed -- every strip is cut into chunks)
-  const int slots = n_chunk > 0 || g_variant == 39 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL, A0F, OPT>, block);
+  if (n_chunk > 0) slots = 0;
   // (measured on MI355X with two halo lanes and non-temporal stores: whole groups first wins
   // from one round of workgroups up -- 2.02 against 2.11 ms at 128 rows x 2^21 columns, 2.06
   // against 2.15 at 256 x 2^20, 0.53 against 0.57 at 64 x 2^20, 1.02-1.04 against 1.03-1.08 at
@@ -246,6 +246,14 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
     args.wg_begin[2] = args.wg_begin[1] + (groups - whole) * chunks_of(tail_chunk);
   }
   for (int k = args.n_phase; k < 3; k++) { args.g0[k] = 0; args.ng[k] = 1; args.len[k] = args.N; args.wg_begin[k + 1] = args.wg_begin[k]; }
+}
+
+template <int MINW, bool DIAG = false, bool ROWS = false, int H = 2, bool NTS = true, bool NTL = false, int A0F = 0, int OPT = 0>
+int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
+{
+  // (tuning variant 39: as if the occupancy query had failed -- every strip is cut into chunks)
+  const int slots = n_chunk > 0 || g_variant == 39 ? 0 : resident_workgroups(fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL, A0F, OPT>, block);
+  schedule_fused2(args, H, block, n_chunk, tail_chunk, slots);
   hipLaunchKernelGGL((fused2_step_kernel<MINW, DIAG, ROWS, H, NTS, NTL, A0F, OPT>), dim3(args.wg_begin[args.n_phase]), dim3(block), 0,
                      launch_stream(), args);
   return (int)hipGetLastError();
@@ -446,6 +454,52 @@ void slb_set_tuning(int v, int nc, int b) { g_variant = v; g_n_chunk = nc; g_blo
 #ifdef SLB_TIMING_VARIANTS
 void slb_debug_set_stamps(unsigned long long *buf) { g_stamps = buf; }
 #endif
+int slb_debug_schedule(int kind, int steps, int N, int col_first, int col_last, int block, int n_chunk, int slots,
+                       int *info, int *cover, int cover_len)
+{
+  if (!info || !cover || N < 1 || col_first < 1 || col_last < col_first || block < 64 || block > 256 || block % 64 != 0 ||
+      (kind != 2 && kind != 3 && kind != 4) || (kind != 2 && steps != 2 && steps != 3))
+    return -1;
+  const int H = 2, per_group = (64 - 2 * H) * 4 * (block / 64);
+  int groups = 0, total = 0;
+  auto tally = [&](auto &sched, int edge_last, int jj0) -> int {
+    groups = (col_last + 1 - jj0 + per_group - 1) / per_group;
+    if ((long long)groups * N > cover_len) return -3;
+    for (int i = 0; i < groups * N; i++) cover[i] = 0;
+    total = sched.wg_begin[sched.n_phase];
+    for (int id = 0; id < total; id++) {
+      const WgPlace wg = place_workgroup(sched, id, edge_last);
+      if (!wg.live) continue;
+      if (wg.bx < 0 || wg.bx >= groups || wg.len < 1) return -2;
+      for (int n = wg.n0; n < wg.n0 + wg.len && n < N; n++) cover[wg.bx * N + n]++;
+    }
+    info[0] = groups; info[1] = sched.n_phase; info[2] = per_group; info[3] = jj0;
+    return total;
+  };
+  if (kind == 2) {
+    Fused2Args a;
+    memset(&a, 0, sizeof(a));
+    a.N = N;
+    for (int q = 0; q < 4; q++) { a.jf[q] = col_first; a.jl[q] = col_last; }
+    schedule_fused2(a, H, block, n_chunk, N >= 128 ? (7 * N + 15) / 16 : 32, slots);
+    return tally(a, 0, a.jj0);
+  }
+  slb_multi_geom g;
+  memset(&g, 0, sizeof(g));
+  g.pitch = (col_last + 2 + 31) / 32 * 32; g.steps = steps;
+  for (int q = 0; q < 2 * steps; q++) { g.j_first[q] = col_first; g.j_last[q] = col_last; }
+  const float *in[4] = {nullptr, nullptr, nullptr, nullptr}, *pers[8] = {};
+  float *out[4] = {nullptr, nullptr, nullptr, nullptr};
+  const float cosines[16] = {};
+  const int saved_N = g_phys.N;
+  g_phys.N = N;
+  int rc;
+  if (steps == 2) { PipeArgs<2> a = make_pipe_args<2>(&g, nullptr, in, pers, pers, out, cosines, H, block, n_chunk, slots, kind == 3); rc = tally(a, a.edge_last, a.jj0); }
+  else            { PipeArgs<3> a = make_pipe_args<3>(&g, nullptr, in, pers, pers, out, cosines, H, block, n_chunk, slots, kind == 3); rc = tally(a, a.edge_last, a.jj0); }
+  g_phys.N = saved_N;
+  return rc;
+}
+
 const char *slb_version(void)          { return "slb2d-gfx950 0.1"; }
 
 int slb_sweep(const slb_slab *slab,
