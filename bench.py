@@ -320,6 +320,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 
+    # Standard output is kept for the one JSON line: whatever libraries print there meanwhile
+    # (gloo announces its connections on it) goes to standard error instead.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     slb = importlib.import_module("super-lattice-boltzmann-2d_amd")
 
@@ -529,7 +535,12 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(n_harm, g_grid, phys, args.cpu_steps)
             out["config1"] = config1_case(slb, torch)
+        sys.stdout.flush()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)              # C-level buffers of the redirected output go where they were meant to
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -87,6 +87,8 @@ def test_bench_starts_its_own_ranks():
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
+    # nothing but that line on standard output, whatever the libraries underneath announce
+    assert r.stdout.strip() == lines[0], r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["repeats"] == 2
     assert "g-grid=131072" in d["config"]["workload"]
