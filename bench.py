@@ -155,6 +155,10 @@ def parse_args(argv=None):
                          "if that driver cannot start -- it never changes silently), torch for the other "
                          "forms.  SLB_DIST_BACKEND=gloo (rehearsals with several ranks on one GPU): the C "
                          "driver's messages go over sockets instead of RCCL")
+    ap.add_argument("--data", choices=("analytic", "stress"), default="analytic",
+                    help="analytic (default): the equilibrium initial state, whose high harmonics are zeros and "
+                         "denormals; stress (one GPU): every array filled with sine products of (n, m), values "
+                         "around 0.1 throughout -- shows whether the rate depends on what the lattice holds")
     ap.add_argument("--no-self-check", action="store_true", help="N > 1: skip the ghost-column check before timing")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-two-sweep", action="store_true", help="skip the two-sweep leg of the default run")
@@ -225,9 +229,30 @@ def median_block(blocks):
     return blocks[order[(len(blocks) - 1) // 2]]
 
 
+def fill_without_tails(sol, torch):
+    """--data stress: every lattice array (a0 included) overwritten with products of sines of (n, m),
+    magnitudes around 0.1 everywhere -- no zeros, no denormals, none of the tails of the analytic
+    state at high harmonics.  Deterministic, no RNG."""
+    import ctypes
+    with open("/proc/self/maps") as f:
+        paths = sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    hip = ctypes.CDLL(paths[0])
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    s = sol.s
+    n = torch.arange(s.N + 1, device="cuda", dtype=torch.float32)[:, None]
+    m = torch.arange(s.pitch, device="cuda", dtype=torch.float32)[None, :]
+    arrays = [s.a0] + [s.a[i] for i in range(4)] + [s.b[i] for i in range(4)]
+    for k, ptr in enumerate(arrays):
+        x = (0.1 + 0.2 * torch.sin(0.37 * n + 0.0113 * m + k) * torch.cos(0.05 * n - 0.0031 * m + 2 * k)).contiguous()
+        assert hip.hipMemcpy(ptr, x.data_ptr(), x.numel() * 4, 3) == 0          # device to device
+    torch.cuda.synchronize()
+
+
 def run_single(args, slb, torch, form, steps, warmup, repeats):
     sol = slb.Solver(0, 1)
     sol.tiptoe()
+    if args.data == "stress":
+        fill_without_tails(sol, torch)
     sol.set_fused({"triple": 3, "double": 2, "fused": 1, "sweeps": 0}[form])
     warm = warmup
     if form in ("double", "triple"):
@@ -334,6 +359,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.data == "stress" and world > 1:
+        raise SystemExit("--data stress fills one GPU's lattice")
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     torch.zeros(1, device="cuda")              # make this device current for the C library too
     # SLB_DIST_BACKEND=gloo: rehearsal of the multi-rank path where RCCL cannot run (several
@@ -481,7 +508,8 @@ def main():
         "repeats": repeats,
         "ms_per_step_min": min(walls) / args.steps * 1e3, "ms_per_step_max": max(walls) / args.steps * 1e3,
         "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (analytic equilibrium initial state, no RNG)",
+        "dtype": "f32", "data": "synthetic (analytic equilibrium initial state, no RNG)" if args.data == "analytic" else
+                                 "synthetic (sine products of (n, m) in every array, no tails, no RNG)",
         "config": {"workload": f"n-harmonics={n_harm} g-grid={g_grid} "
                                f"({g_grid // world} columns per GPU, phi_y slabs) "
                                f"omega=100 B={phys['B']:.6g} dt=0.001, 2 sweeps per step",

@@ -130,3 +130,17 @@ def test_bench_takes_odd_step_counts(gpus, steps, warmup):
     assert d["n_gpus"] == gpus and d["steps"] == steps and d["warmup"] == warmup and d["value"] > 0
     # the launch time of the dominant kernel comes from blocks of whole launches whatever --steps is
     assert d["roofline"]["kernel"] == "ring_step_kernel" and d["roofline"]["avg_launch_ms"] > 0
+
+
+def test_bench_stress_data_fills_every_array():
+    """--data stress: same contract, the line says what the lattice held."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--repeats", "2",
+                        "--g-grid-per-gpu", "65536", "--no-cpu", "--no-two-sweep", "--data", "stress"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip())
+    assert "sine products" in d["data"] and d["value"] > 0 and d["roofline"]["kernel"] == "ring_step_kernel"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--data", "stress",
+                        "--g-grid-per-gpu", "65536"], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env={**os.environ, "SLB_DIST_BACKEND": "gloo"})
+    assert r.returncode != 0
