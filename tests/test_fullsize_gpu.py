@@ -44,6 +44,7 @@ def _check_step_on_window(sol, slb, oracle, p, c0, c1):
     (128, 1 << 23, 2),       # config 4 on a single GPU (39 GB)
     (256, 1 << 20, 2),       # between the named shapes: another row-chunk length
     (130, 300001, 2),        # odd sizes: partial last chunk, ragged last strip
+    (64, 1 << 25, 2),        # 8.7 GB per array (the reference's int byte counts end at 2 GiB): offsets beyond 2^31 floats
 ])
 def test_full_shape_windows_bit_exact(slb, oracle, N, M, steps):
     p = oracle.make_params(N=N, M=M, B=4000.0 / M, omega=100.0)
@@ -140,6 +141,7 @@ def _check_double_step_on_window(sol, slb, oracle, p, c0, c1, rows=None):
     (128, 1 << 23),          # config 4 on a single GPU: eleven rounds
     (128, 800003),           # just over one round of workgroups
     (64, 1 << 18),           # config 2's shape: every strip cut into short chunks
+    (64, 1 << 25),           # 8.7 GB per array
 ])
 def test_full_shape_double_step_windows_bit_exact(slb, oracle, N, M, with_rows):
     """The program's and the benchmark's default kernel under the launch schedule those shapes
@@ -232,6 +234,7 @@ def _check_multi_step_on_window(sol, slb, oracle, p, c0, c1, S, rows=None):
     (128, 800003),
     (64, 1 << 19),           # the narrowest lattice the program runs in threes
     (33, 600011),            # odd row count, ragged right edge
+    (64, 1 << 25),           # 8.7 GB per array: row offsets beyond 2^31 floats, 34 rounds of workgroups
 ])
 def test_full_shape_triple_step_windows_bit_exact(slb, oracle, N, M, with_rows):
     """The default of the program and of the benchmark on wide lattices -- three iterations per
