@@ -90,6 +90,19 @@ def _one_and_many(solver_bin, tmp_path, args, ranks, stdin_text=None, env=None):
     return one, many
 
 
+@pytest.mark.parametrize("per_launch", ["2", "3"])
+def test_narrowest_slabs_and_the_refusal_below_them(per_launch, tmp_path, solver_bin):
+    """Slabs of exactly twelve columns (two edge ranges of six, no interior left) give the single-GPU
+    record; narrower ones are refused by every rank with the reason, and the program ends non-zero
+    instead of waiting for anyone."""
+    args = BASE + ["omega=100", "B=0.5", "dt=0.001", "n-harmonics=8", "g-grid=36", "t-max=0.02", "o=out.txt"]
+    one, many = _one_and_many(solver_bin, tmp_path, args, 3, env={"SLB_STEPS_PER_LAUNCH": per_launch})
+    assert (tmp_path / "one" / "out.txt").read_bytes() == (tmp_path / "many" / "out.txt").read_bytes()
+    bad = subprocess.run([solver_bin] + args + ["ranks=4"], cwd=tmp_path / "many", capture_output=True, text=True,
+                         timeout=120, env={**os.environ, "SLB_STEPS_PER_LAUNCH": per_launch})
+    assert bad.returncode != 0 and "at least 12 columns" in bad.stderr
+
+
 MODES = ["E_dc=1", "E_omega=0.1", "mu=5", "alpha=1", "PhiYmin=-4", "PhiYmax=4", "dt=0.001", "quiet=1", "o=out.txt"]
 
 
