@@ -394,7 +394,8 @@ void  slb_pop_stream(void);
  *   the two quotients of a point, where the run's denominators lie between 0.5 and 2^100).
  *   slb_step_multi (default at three steps per launch: the LDS-ring kernel with branch-free steady
  *   passes): 1 = the register-history kernel at any S; 2 = the default kernel with one round of whole
- *   column strips fewer, the strips left over in chunks of n_chunk rows (measured slower); 32 / 33 / 34 = that kernel with two columns
+ *   column strips fewer, the strips left over in chunks of n_chunk rows (measured slower); 3 = on a lattice of less
+ *   than one round of workgroups whole column strips all the same (edge strip groups first; measured no faster); 32 / 33 / 34 = that kernel with two columns
  *   per lane instead of four, with a register budget of 2 / 3 / 4 waves per SIMD; 35 / 36 / 37 = one
  *   column per lane, budget of 2 / 4 / 8 waves per SIMD; 70..75 = the scheduled kernel with its
  *   stage outputs in registers, 80..84 = in an LDS ring per wave (S = 2, 3); 90 / 91 = the ring

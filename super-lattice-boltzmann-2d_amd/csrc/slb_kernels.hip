@@ -268,7 +268,8 @@ int launch_fused2(Fused2Args &args, int block, int n_chunk, int tail_chunk)
 template <int S>
 PipeArgs<S> make_pipe_args(const slb_multi_geom *g, const float *a0, const float *const *in, const float *const *pers_a,
                            const float *const *pers_b, float *const *out, const float *cosines, int H, int block,
-                           int n_chunk, int slots, bool edge_first = false, int fewer_rounds = 0, int rest_chunk = 0)
+                           int n_chunk, int slots, bool edge_first = false, int fewer_rounds = 0, int rest_chunk = 0,
+                           bool sub_round_whole = false)
 {
   constexpr int Q = 2 * S;
   PipeArgs<S> s;
@@ -293,9 +294,12 @@ PipeArgs<S> make_pipe_args(const slb_multi_geom *g, const float *a0, const float
   auto chunks_of = [&](int len) { return (s.N + len - 1) / len; };
   if (n_chunk > 0) slots = 0;
   s.edge_last = 0;
-  const bool edges = edge_first && slots > 0 && groups >= slots + 2;
+  // (tuning: on a lattice of less than one round of workgroups, whole strips all the same -- no row is
+  // formed twice, but the device is not full)
+  const bool sub = sub_round_whole && edge_first && slots > 0 && n_chunk <= 0 && groups >= 3 && groups < slots + 2;
+  const bool edges = edge_first && slots > 0 && (groups >= slots + 2 || sub);
   const int inner = edges ? groups - 2 : groups;          // strip groups other than the two at the ends
-  int whole = slots > 0 && inner >= slots ? inner / slots * slots : 0;
+  int whole = slots > 0 && inner >= slots ? inner / slots * slots : (sub ? inner : 0);
   int tail_chunk = s.N >= 128 ? (7 * s.N + 15) / 16 : 32;
   // (tuning: fewer_rounds of whole strips less, the strips left over in chunks of rest_chunk rows)
   if (fewer_rounds > 0 && whole >= (fewer_rounds + 1) * slots) {
@@ -374,7 +378,7 @@ int launch_ring(const slb_multi_geom *g, const float *a0, const float *const *in
   const int slots = n_chunk > 0 && g_variant != 2 ? 0 : resident_workgroups(ring_step_kernel<S, MINW, ROWS, DIV2, X>, block);
   RingArgs<S> s;
   if (g_variant == 2) s.p = make_pipe_args<S>(g, a0, in, pers_a, pers_b, out, cosines, 2, block, 0, slots, true, 1, n_chunk);
-  else                s.p = make_pipe_args<S>(g, a0, in, pers_a, pers_b, out, cosines, 2, block, n_chunk, slots, true);
+  else                s.p = make_pipe_args<S>(g, a0, in, pers_a, pers_b, out, cosines, 2, block, n_chunk, slots, true, 0, 0, g_variant == 3);
   for (int i = 0; i < S; i++) s.rows[i] = ROWS && rows ? rows[i] : nullptr;
   s.stamps = g_stamps;
   hipLaunchKernelGGL((ring_step_kernel<S, MINW, ROWS, DIV2, X>), dim3(s.p.wg_begin[s.p.n_phase]), dim3(block), 0, launch_stream(), s);
@@ -959,7 +963,7 @@ static int step_multi_impl(const slb_multi_geom *g, const float *a0, const float
   // Three steps per launch: the LDS-ring kernel (ring_step_kernel), the fastest form on MI355X from about
   // one round of workgroups up (tuning variant 1 keeps the register-history kernel, multi_step_kernel).
   // With rows, the ring kernel is the only three-step form that hands them out.
-  if (g->steps == 3 && block == 256 && (v == 0 || v == 2 || rows)) {
+  if (g->steps == 3 && block == 256 && (v == 0 || v == 2 || v == 3 || rows)) {
     const int nc = g_n_chunk;
     const bool d2 = shared_division_ok(g->m_offset, g->pitch);
     if (rows) return d2 ? launch_ring<3, 2, true, true>(g, a0, in, pers_a, pers_b, out, cosines, nc, rows)
