@@ -385,7 +385,7 @@ def test_double_step_bit_exact(slb, oracle, N, M, B, omega, pairs, n_chunk):
 
 @pytest.mark.parametrize("S,variant", [(1, 0), (2, 0), (3, 0), (4, 0), (2, 34), (3, 32), (3, 33), (4, 32), (2, 35), (2, 37), (3, 36), (4, 35), (4, 36),
                                        (2, 70), (2, 73), (3, 71), (3, 72), (3, 73), (3, 74), (3, 75),
-                                       (2, 80), (2, 82), (2, 84), (3, 80), (3, 81), (3, 83), (2, 90), (2, 91), (3, 90), (3, 1)])
+                                       (2, 80), (2, 82), (2, 84), (3, 80), (3, 81), (3, 83), (2, 90), (2, 91), (3, 90), (3, 1), (3, 2), (3, 3)])
 @pytest.mark.parametrize("N,M,B,omega,n_chunk", [
     (1, 5, 0.5, 3.0, 0), (2, 61, 0.05, 100.0, 0), (5, 61, 0.05, 100.0, 2), (7, 300, 0.4, 10.0, 3),
     (32, 4096, 1.0, 1.0, 0), (33, 1000, 0.5, 30.0, 5), (16, 239, 0.3, 10.0, 0), (16, 240, 0.3, 10.0, 8),
