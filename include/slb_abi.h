@@ -210,7 +210,8 @@ int slb_selftest_division(unsigned long long count, unsigned seed, unsigned long
  * schedule a multi-step kernel would get for rows 0..N-1 and columns col_first..col_last on a
  * device that holds `slots` of its workgroups at once (0: unknown), and who forms what under it.
  * kind 2: the double step's schedule; 3: the S-step kernels' (steps = 2 or 3) with the two edge
- * strip groups first; 4: the same without.  block: threads per workgroup; n_chunk > 0: every
+ * strip groups first; 4: the same without; 5: as 3, with whole strips also below one round of workgroups
+ * (tuning variant 3).  block: threads per workgroup; n_chunk > 0: every
  * strip group cut into chunks of that many rows.  Returns the number of workgroups (< 0: bad
  * arguments, a strip group out of range, cover too short); info[0..3] = strip groups, phases,
  * columns per strip group, first column of strip group 0; cover[g * N + n] = how many workgroups

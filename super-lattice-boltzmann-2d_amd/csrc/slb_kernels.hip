@@ -462,7 +462,7 @@ int slb_debug_schedule(int kind, int steps, int N, int col_first, int col_last, 
                        int *info, int *cover, int cover_len)
 {
   if (!info || !cover || N < 1 || col_first < 1 || col_last < col_first || block < 64 || block > 256 || block % 64 != 0 ||
-      (kind != 2 && kind != 3 && kind != 4) || (kind != 2 && steps != 2 && steps != 3))
+      kind < 2 || kind > 5 || (kind != 2 && steps != 2 && steps != 3))
     return -1;
   const int H = 2, per_group = (64 - 2 * H) * 4 * (block / 64);
   int groups = 0, total = 0;
@@ -498,8 +498,8 @@ int slb_debug_schedule(int kind, int steps, int N, int col_first, int col_last, 
   const int saved_N = g_phys.N;
   g_phys.N = N;
   int rc;
-  if (steps == 2) { PipeArgs<2> a = make_pipe_args<2>(&g, nullptr, in, pers, pers, out, cosines, H, block, n_chunk, slots, kind == 3); rc = tally(a, a.edge_last, a.jj0); }
-  else            { PipeArgs<3> a = make_pipe_args<3>(&g, nullptr, in, pers, pers, out, cosines, H, block, n_chunk, slots, kind == 3); rc = tally(a, a.edge_last, a.jj0); }
+  if (steps == 2) { PipeArgs<2> a = make_pipe_args<2>(&g, nullptr, in, pers, pers, out, cosines, H, block, n_chunk, slots, kind != 4, 0, 0, kind == 5); rc = tally(a, a.edge_last, a.jj0); }
+  else            { PipeArgs<3> a = make_pipe_args<3>(&g, nullptr, in, pers, pers, out, cosines, H, block, n_chunk, slots, kind != 4, 0, 0, kind == 5); rc = tally(a, a.edge_last, a.jj0); }
   g_phys.N = saved_N;
   return rc;
 }

@@ -37,7 +37,7 @@ def _check(lib, kind, steps, N, col_first, col_last, block, n_chunk, slots):
     return total, groups, phases
 
 
-@pytest.mark.parametrize("kind,steps", [(2, 2), (3, 2), (3, 3), (4, 2), (4, 3)])
+@pytest.mark.parametrize("kind,steps", [(2, 2), (3, 2), (3, 3), (4, 2), (4, 3), (5, 3)])
 def test_every_row_of_every_strip_group_once_random_shapes(lib, kind, steps):
     rng = np.random.default_rng(100 * kind + steps)
     seen_phases = set()
@@ -54,7 +54,7 @@ def test_every_row_of_every_strip_group_once_random_shapes(lib, kind, steps):
         n_chunk = int(rng.choice([0, 0, 0, 1, 3, 16, 43, 64, 200]))
         _, _, phases = _check(lib, kind, steps, N, col_first, col_last, block, n_chunk, slots)
         seen_phases.add(phases)
-    assert seen_phases >= ({1, 2, 3} if kind == 3 else {1, 2}), seen_phases
+    assert seen_phases >= ({1, 2, 3} if kind in (3, 5) else {1, 2}), seen_phases
 
 
 @pytest.mark.parametrize("N,cols,slots,expect", [
@@ -76,6 +76,6 @@ def test_bad_arguments_are_refused(lib):
     info = (C.c_int * 4)()
     cover = (C.c_int * 16)()
     assert lib.slb_debug_schedule(3, 3, 128, 1, 1 << 20, 256, 0, 512, info, cover, 16) == -3     # cover too short
-    assert lib.slb_debug_schedule(5, 3, 8, 1, 100, 256, 0, 0, info, cover, 16) == -1
+    assert lib.slb_debug_schedule(6, 3, 8, 1, 100, 256, 0, 0, info, cover, 16) == -1
     assert lib.slb_debug_schedule(3, 4, 8, 1, 100, 256, 0, 0, info, cover, 16) == -1
     assert lib.slb_debug_schedule(3, 3, 0, 1, 100, 256, 0, 0, info, cover, 16) == -1
