@@ -147,7 +147,7 @@ def test_program_display77_identical(solver_bin, oracle, tmp_path, per_launch):
 
 
 def test_program_display77_config2_full_size_identical(solver_bin, oracle, tmp_path):
-    """BASELINE config 2 at its full size (display=77, n-harmonics=64, g-grid=262144, B=0.015,
+    """The second benchmark configuration at its full size (display=77, n-harmonics=64, g-grid=262144, B=0.015,
     113 iterations, 11 records; reference: src/boltzmann_c_solver.c:178-186, 298-331): all 22
     lines of the trace and the norm log equal the CPU oracle's, which runs the same lattice on
     the host's cores."""
@@ -166,7 +166,7 @@ def test_program_display77_config2_full_size_identical(solver_bin, oracle, tmp_p
 
 
 def test_program_display4_config3_shape_averaged_throughout(solver_bin, oracle, tmp_path):
-    """BASELINE config 3's shape as a program (display=4, n-harmonics=128, g-grid=1048576,
+    """The headline benchmark shape as a program (display=4, n-harmonics=128, g-grid=1048576,
     omega=100, t-max=0.001: 64 iterations, all but the first averaged): the double-step kernel
     with the row buffers under the whole-strips-first schedule feeds the parallel exact sums,
     and the record -- instantaneous sums, norm, period averages, absorption -- equals the CPU
