@@ -14,6 +14,7 @@ K=$PKG/csrc/slb_kernels.o          # (object files do not travel to a GPU box: b
 [ -f $K ] || { K=$B/slb_kernels.o; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 -c $PKG/csrc/slb_kernels.hip -o $K 2> $B/hipcc.log; }
 gcc $SAN -shared -fPIC -o $B/libslb2d.so $K $(ls $B/*.o | grep -v slb_kernels.o) -L/opt/rocm/lib -lamdhip64 -lstdc++ -lm -ldl -lpthread -Wl,-rpath,/opt/rocm/lib
 gcc -std=gnu99 $SAN -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o $B/boltzmann_solver $PKG/host/boltzmann_solver.c -L$B -lslb2d -Wl,-rpath,$R/$B -Wl,-rpath,/opt/rocm/lib -lm
+echo "sanitizer runtime linked: $(ldd $B/boltzmann_solver | grep -c -E "libasan|libubsan") libraries, $(nm -D $B/libslb2d.so | grep -c __asan_report) report entry points referenced by the library"
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0:log_path=$R/$O/asan
 export UBSAN_OPTIONS=print_stacktrace=1:log_path=$R/$O/ubsan
 C="E_dc=1 E_omega=0.1 mu=5 alpha=1 PhiYmin=-4 PhiYmax=4 dt=0.001 quiet=1"
@@ -40,3 +41,4 @@ run r3d8    display=8 omega=100 B=0.5 n-harmonics=8 g-grid=61 t-max=0.01 ranks=3
 STDIN=$R/$O/records.txt run r3stdin display=4 omega=100 B=0.5 n-harmonics=8 g-grid=1001 t-max=0.02 read-from=stdin ranks=3 $C
 echo "sanitizer reports:"; ls $O | grep -E "^(asan|ubsan)\." || echo "  none"
 for f in $O/asan.* $O/ubsan.*; do [ -f "$f" ] && { echo "== $f"; head -40 "$f"; }; done 2>/dev/null | head -150
+rm -rf $B $O/*.ref $O/*.san
