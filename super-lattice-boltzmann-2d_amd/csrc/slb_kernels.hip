@@ -932,10 +932,13 @@ static int step_multi_impl(const slb_multi_geom *g, const float *a0, const float
   // tuning variants 90 / 91: the ring kernel with the branch-free steady passes (ring_step_kernel),
   // register budget of 2 / 3 waves per SIMD
 #ifdef SLB_TIMING_VARIANTS
-  // timing builds: 92 = the rows of a pass requested in that pass, 93 = no stores, 95 = time stamps per wave
+  // timing builds: 92 = the rows of a pass requested in that pass, 93 = no stores, 95 = time stamps per wave,
+  // 96 = a strip's last passes left out, 94 = those passes in the branch-free body (wrong results in the last rows)
   if (v == 92 && g->steps == 3) return launch_ring<3, 2, false, true, 1>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
   if (v == 93 && g->steps == 3) return launch_ring<3, 2, false, true, 2>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
   if (v == 95 && g->steps == 3) return launch_ring<3, 2, false, true, 4>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
+  if (v == 96 && g->steps == 3) return launch_ring<3, 2, false, true, 8>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
+  if (v == 94 && g->steps == 3) return launch_ring<3, 2, false, true, 16>(g, a0, in, pers_a, pers_b, out, cosines, g_n_chunk);
 #endif
   if ((v == 90 || v == 91) && (g->steps == 2 || g->steps == 3)) {
     if (block != 256) { fprintf(stderr, "slb_step_multi: the LDS ring is laid out for 256 threads\n"); return -1; }

@@ -590,16 +590,19 @@ void slb_solver_multi_step_rows(slb_solver *s, int S, float *const *rows)
 
 /* How many loop iterations a launch of the time loop should take on this slab: 3 where the
  * three-step kernel has the lattice to fill the device, else 2.  Measured on MI355X (updates per
- * second, two against three steps per launch): 2.4e11 / 2.6e11 at 64 harmonics x 2^19 columns,
- * 2.5e11 / 3.1e11 at 128 x 2^19, 2.35e11 / 2.7e11 at 32 x 2^20, 2.6e11 / 3.9e11 at 512 x 2^20; but
- * 2.4e11 / 2.2e11 at 128 x 2^18, 2.1e11 / 1.9e11 at 64 x 2^18 and 2.6e11 / 2.3e11 at 16 x 2^21.
- * SLB_STEPS_PER_LAUNCH=1..3 overrides. */
+ * second, two against three steps per launch): 2.4e11 / 2.9e11 at 64 harmonics x 2^19 columns,
+ * 2.2e11 / 3.4e11 at 128 x 2^19, 2.25e11 / 3.0e11 at 32 x 2^20, 2.6e11 / 3.9e11 at 512 x 2^20,
+ * 2.2e11 / 2.5e11 at 32 x 2^19; among the narrower lattices 2.4e11 / 2.6e11 at 128 x 2^18,
+ * 2.3e11 / 2.4e11 at 96 x 2^18, 2.3e11 / 2.6e11 at 256 x 2^17, 2.2e11 / 2.5e11 at 512 x 2^16 and
+ * 2.2e11 / 2.7e11 at 2048 x 2^15, but a tie at 64 x 2^18 and at 128 x 2^17 (2.1e11 both) and
+ * 2.6e11 / 2.3e11 at 16 x 2^21: three from 32 harmonics up where the lattice has 2^19 columns
+ * or 24 million points.  SLB_STEPS_PER_LAUNCH=1..3 overrides. */
 int slb_solver_steps_per_launch(const slb_solver *s)
 {
   const char *e = getenv("SLB_STEPS_PER_LAUNCH");
   if (e && e[0] >= '1' && e[0] <= '3' && e[1] == 0) return e[0] - '0';
   const long waves = ((long)s->W + 239) / 240;
-  return s->N >= 32 && waves >= 2048 ? 3 : 2;
+  return s->N >= 32 && (waves >= 2048 || (long)s->N * (long)s->W >= 24000000L) ? 3 : 2;
 }
 
 int slb_solver_run_timed(slb_solver *s, int steps, float *ms)

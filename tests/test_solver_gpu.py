@@ -524,6 +524,25 @@ def test_multi_step_hands_out_the_rows_av_reads(slb, oracle, S, N, M, B, omega, 
         orc.close()
 
 
+@pytest.mark.parametrize("N,M,expected", [(64, 262144, 2), (128, 262144, 3), (96, 262144, 3), (32, 524288, 3), (16, 2097152, 2),
+                                          (512, 65536, 3), (128, 131072, 2), (32, 4096, 2), (128, 1 << 20, 3)])
+def test_steps_per_launch_follows_the_measured_rule(slb, N, M, expected, monkeypatch):
+    """Three iterations per launch from 32 harmonics up where the lattice has 2^19 columns or 24 million
+    points (where the three-step kernel was measured faster), two elsewhere; the environment overrides."""
+    monkeypatch.delenv("SLB_STEPS_PER_LAUNCH", raising=False)
+    slb.configure(N=N, M=M, E_dc=1.0, E_omega=0.1, omega=100.0, mu=5.0, alpha=1.0, B=4000.0 / M,
+                  PhiYmin=-4.0, PhiYmax=4.0, dt=0.001)
+    sol = slb.Solver()
+    try:
+        assert sol.steps_per_launch() == expected
+        monkeypatch.setenv("SLB_STEPS_PER_LAUNCH", "2")
+        assert sol.steps_per_launch() == 2
+        monkeypatch.setenv("SLB_STEPS_PER_LAUNCH", "3")
+        assert sol.steps_per_launch() == 3
+    finally:
+        sol.close()
+
+
 def _hip_runtime():
     import ctypes
     with open("/proc/self/maps") as f:
